@@ -1,0 +1,139 @@
+"""Iterator yielding (input_nodes, seeds, blocks, features) per training step.
+
+Mirror of COALA-GNN-Setup/COALA_GNN/COALA_GNN_DataLoader.py (reference): COALA_GNN_Node_Distribution_Scheduler :8-75,
+SSD_INFO :80-90, COALA_GNN_DataLoader :92-177 -- same names, arguments, cadence and double buffering.
+`graph_sampler` only needs .sample(graph, seed_ids) returning a tuple whose first element is the int64 input-node
+tensor (a DGL sampler object works when dgl imports; COALA_GNN.sampler.NeighborSampler is the native one)."""
+import threading
+
+import torch
+
+from .COALA_GNN_Manager import COALA_GNN_Manager
+
+__all__ = ["COALA_GNN_Node_Distribution_Scheduler", "SSD_INFO", "COALA_GNN_DataLoader"]
+
+
+class COALA_GNN_Node_Distribution_Scheduler(object):
+    def __init__(self, node_distributor, ssd_gnn_manager, refresh_counter=8):
+        self.node_distributor = node_distributor
+        self.ssd_gnn_manager = ssd_gnn_manager
+        self.metadata_reuse_counter = 0
+        self.refresh_counter = refresh_counter
+        self.cache_color_gathered_header = 0
+        self.distribute_thread = None
+        self.cache_meta_gather_thread = None
+        # num_colors + 1 entries: colours run 1..num_colors
+        self.cache_meta_tensor = torch.zeros(self.node_distributor.num_colors + 1, dtype=torch.int32)
+
+    def run(self, is_last: bool):  # COALA_GNN_DataLoader.py:27-75
+        nd = self.node_distributor
+        comm = nd.comm_manager
+        if comm.is_master:
+            if self.distribute_thread is None:  # first stage of the distribution pipeline
+                self.distribute_thread = threading.Thread(target=nd.parse_domain_training_nodes,
+                                                          args=(self.cache_color_gathered_header,))
+                self.distribute_thread.start()
+            self.distribute_thread.join()
+            self.distribute_thread = None
+
+        distributed_node_index = nd.parsed_training_nodes_buffer[nd.parsed_training_nodes_buffer_header]
+        comm.broadcast_training_nodes(distributed_node_index)
+        nd.parsed_training_nodes_buffer_header = (nd.parsed_training_nodes_buffer_header + 1) % 2
+
+        if self.metadata_reuse_counter == self.refresh_counter:
+            self.metadata_reuse_counter = 0
+            if self.cache_meta_gather_thread is not None:
+                self.cache_meta_gather_thread.join()
+                nd.cache_color_db_header = int((nd.cache_color_db_header + 1) % 2)
+            self.ssd_gnn_manager.COALA_GNN_Cache.get_cache_data(self.cache_meta_tensor.data_ptr(),
+                                                                self.cache_meta_tensor.numel())
+            self.cache_color_gathered_header = int((nd.cache_color_db_header + 1) % 2)
+            self.cache_meta_gather_thread = threading.Thread(target=nd.gather_cache_meta, args=(self.cache_meta_tensor,))
+            self.cache_meta_gather_thread.start()
+
+        if comm.is_master and not is_last:
+            self.distribute_thread = threading.Thread(target=nd.parse_domain_training_nodes,
+                                                      args=(self.cache_color_gathered_header,))
+            self.distribute_thread.start()
+
+        self.metadata_reuse_counter += 1
+        local_r = comm.local_rank
+        # clone: the double buffer is overwritten two steps later while the slice may still be in use
+        return distributed_node_index[(local_r * nd.batch_size):((local_r + 1) * nd.batch_size)].clone()
+
+    def drain(self):
+        for t in (self.distribute_thread, self.cache_meta_gather_thread):
+            if t is not None:
+                t.join()
+        self.distribute_thread = None
+        self.cache_meta_gather_thread = None
+
+
+class SSD_INFO(object):  # COALA_GNN_DataLoader.py:80-90
+    def __init__(self, num_ssds, page_size, num_elems, ssd_read_offset):
+        self.num_ssds = num_ssds
+        self.num_elems = num_elems
+        self.ssd_read_offset = ssd_read_offset
+        self.page_size = page_size
+
+
+class COALA_GNN_DataLoader(torch.utils.data.DataLoader):
+    def __init__(self, SSD_info, node_distributor, graph, graph_sampler, batch_size, dim, fan_out, cache_size, device,
+                 refresh_counter=10, cache_backend="nvshmem", sim_buf=None, shuffle=False, num_rows=None, profile=False):
+        # like the reference, torch's DataLoader.__init__ is never called: this is a plain iterator
+        self.refresh_counter = refresh_counter
+        self.sampler = graph_sampler
+        self.batch_size = batch_size
+        self.g = graph
+        self.SSD_info = SSD_info
+        self.cache_backend = cache_backend
+        self.node_distributor = node_distributor
+        self.device = device
+
+        self.COALA_GNN_Manager = COALA_GNN_Manager(
+            node_distributor=node_distributor, page_size=SSD_info.page_size, num_ssds=SSD_info.num_ssds,
+            num_elems=SSD_info.num_elems, ssd_read_offset=SSD_info.ssd_read_offset, cache_size=cache_size,
+            batch_size=batch_size, fan_out=fan_out, dim=dim, MPI_comm_manager=node_distributor.comm_manager, device=device,
+            cache_backend=cache_backend, sim_buf=sim_buf, num_rows=num_rows, profile=profile)
+        self.scheduler = COALA_GNN_Node_Distribution_Scheduler(node_distributor=self.node_distributor,
+                                                               ssd_gnn_manager=self.COALA_GNN_Manager,
+                                                               refresh_counter=self.refresh_counter)
+        self.counter = 0
+        self.index_len = len(self.node_distributor.index_tensor)
+        self.total_count = int(self.index_len / self.node_distributor.global_batch_size) - 1  # :141
+
+    def __setattr__(self, name, value):  # torch's DataLoader guards some attribute names after __init__; we never ran it
+        object.__setattr__(self, name, value)
+
+    def __iter__(self):
+        return self
+
+    def __len__(self):
+        return max(self.total_count, 0)
+
+    def __next__(self):  # COALA_GNN_DataLoader.py:149-167
+        if self.counter >= self.total_count:
+            self.scheduler.drain()  # the reference resets while a distributor thread may still run
+            self.node_distributor.reset()
+            self.counter = 0
+            raise StopIteration
+        # last step of the epoch: do not launch a distributor thread past the end of the id list (the
+        # reference's is_last test compares a step counter with the id count and never fires)
+        is_last_iter = self.counter + 1 >= self.total_count
+        distributed_index = self.scheduler.run(is_last_iter).to(self.device)
+        batch = self.sampler.sample(self.g, distributed_index)
+        self.counter += 1
+        return self.COALA_GNN_Manager.fetch_feature(batch)
+
+    def print_stats(self):  # :170-174
+        self.COALA_GNN_Manager.print_stats()
+        agg_time = self.COALA_GNN_Manager.get_aggregate_time()
+        print(f"Aggregation time: {agg_time}")
+        self.COALA_GNN_Manager.aggregation_timer = 0.0
+
+    def __del__(self):
+        try:
+            self.scheduler.drain()
+            del self.COALA_GNN_Manager
+        except Exception:
+            pass

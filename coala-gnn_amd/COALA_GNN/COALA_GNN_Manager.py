@@ -1,0 +1,191 @@
+"""fetch_feature orchestration: isolated cache, or the owner-partitioned cache with RCCL all-to-all-v over xGMI.
+
+Mirror of COALA-GNN-Setup/COALA_GNN/COALA_GNN_Manager.py (reference): COALA_GNN_Manager :44-230 with the same constructor
+and methods; NVShmem_Tensor_Manager :8-40 becomes a thin holder of torch-owned HBM buffers (no cupy, no symmetric heap).
+
+Backends (reference strings kept):
+  "isolated" -- each GPU caches what it touches: one call into the probe+gather / rank / fill kernels.
+  "nccl"     -- owner = id % G; ids and rows move with torch.distributed all_to_all_single (RCCL on GPU tensors).
+  "nvshmem"  -- same partitioning; NVSHMEM's device-initiated puts do not exist here, so it rides the same exchange
+                through SSD_GNN_NVSHMEM_Cache.send_requests / read_feature (the reference's call sequence, :131-132).
+Per minibatch the exchange is: route (stable bucketing on the GPU) -> all-to-all of G counts -> ONE host read of the
+2G counts -> all-to-all-v of ids (exact sizes) -> owner serve (one batch: concatenation in source-rank order) ->
+all-to-all-v of rows -> un-permute.  The reference instead moves full-capacity id buffers (:159-163) and G(G-1) serial
+send/recv pairs (:194-203).
+"""
+import time
+
+import torch
+import torch.distributed as dist
+
+from COALA_GNN_Pybind import NVSHMEM_Manager, SSD_GNN_SSD_Controllers, SSD_GNN_NVSHMEM_Cache, Isolated_Cache
+
+__all__ = ["COALA_GNN_Manager", "NVShmem_Tensor_Manager", "AllToAllExchange"]
+
+
+class NVShmem_Tensor_Manager(object):
+    """COALA_GNN_Manager.py:8-40.  Owns the per-step output buffer ring and the request buffer (plain HBM)."""
+
+    def __init__(self, max_rows, dim, n_gpus, device, ring=2):
+        self.device = device
+        self.dim = dim
+        self.batch = [torch.empty((max_rows, dim), dtype=torch.float32, device=device) for _ in range(ring)]
+        self.index_tensor = torch.empty((n_gpus, max_rows * 2), dtype=torch.int64, device=device)
+        self._turn = 0
+
+    def get_batch_tensor(self, shape):
+        # ring of buffers: the tensor returned for step t stays valid while step t+1 is being fetched (the reference
+        # returns a view of ONE symmetric buffer every step, COALA_GNN_Manager.py:127-128)
+        buf = self.batch[self._turn]
+        self._turn = (self._turn + 1) % len(self.batch)
+        return buf[: shape[0]]
+
+    def get_index_tensor(self):
+        return self.index_tensor
+
+    def get_index_tensor_ptr(self):
+        return self.index_tensor.data_ptr()
+
+
+class AllToAllExchange(object):
+    """ids out / rows back over one process group.  `ops` provides the device primitives as pointer-level calls
+    (route, serve, scatter): a COALA_GNN_Pybind cache object in the product; tests may inject another provider to
+    exercise this host logic with gloo on CPU tensors."""
+
+    def __init__(self, group, rank, world, dim, device):
+        self.group, self.rank, self.world, self.dim, self.device = group, rank, world, dim, device
+        self._pending = None
+        self.counts = torch.zeros(world, dtype=torch.int64, device=device)
+        self.offsets = torch.zeros(world + 1, dtype=torch.int64, device=device)
+        self.recv_counts = torch.zeros(world, dtype=torch.int64, device=device)
+        self.last_send_counts = None
+        self.last_recv_counts = None
+
+    def _a2a(self, out, inp, out_splits=None, in_splits=None):
+        if self.world == 1:
+            out.copy_(inp)
+        else:
+            dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
+
+    def send_requests(self, ops, idx_ptr, n, req_ptr, max_index):
+        """route + count exchange + id exchange.  ssd_gnn_cache.cuh:111-129 / COALA_GNN_Manager.py:152-165."""
+        n = int(n)
+        dev = self.device
+        node = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+        mp = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+        ops.route(idx_ptr, n, self.world, node.data_ptr(), mp.data_ptr(), self.counts.data_ptr(), self.offsets.data_ptr(), 0)
+        self._a2a(self.recv_counts, self.counts)
+        both = torch.stack([self.counts, self.recv_counts]).cpu()  # the one host synchronisation of the step
+        send_c, recv_c = both[0].tolist(), both[1].tolist()
+        total_recv = int(sum(recv_c))
+        recv_ids = torch.empty(max(total_recv, 1), dtype=torch.int64, device=dev)
+        self._a2a(recv_ids[:total_recv], node[:n], recv_c, send_c)
+        self._pending = (n, node, mp, send_c, recv_c, recv_ids, total_recv)
+        self.last_send_counts, self.last_recv_counts = send_c, recv_c
+
+    def read_feature(self, ops, out_ptr, req_ptr, max_index):
+        """serve + row exchange + un-permute.  ssd_gnn_cache.cuh:132-174 / COALA_GNN_Manager.py:167-209."""
+        n, node, mp, send_c, recv_c, recv_ids, total_recv = self._pending
+        self._pending = None
+        dev = self.device
+        rows_send = torch.empty((max(total_recv, 1), self.dim), dtype=torch.float32, device=dev)
+        ops.serve(rows_send.data_ptr(), recv_ids.data_ptr(), total_recv)
+        rows_recv = torch.empty((max(n, 1), self.dim), dtype=torch.float32, device=dev)
+        self._a2a(rows_recv[:n], rows_send[:total_recv], send_c, recv_c)
+        ops.scatter(out_ptr, rows_recv.data_ptr(), mp.data_ptr(), n)
+        self._keep = (rows_recv, mp)  # until the next step: scatter is stream-ordered, torch's allocator is too
+
+    def fetch(self, ops, out_ptr, idx_ptr, n, max_index=0):
+        self.send_requests(ops, idx_ptr, n, 0, max_index)
+        self.read_feature(ops, out_ptr, 0, max_index)
+
+
+class COALA_GNN_Manager(object):
+    def __init__(self, node_distributor, num_ssds, page_size, num_elems, ssd_read_offset, cache_size,  # MB
+                 batch_size, fan_out, dim, MPI_comm_manager, device, cache_backend="nvshmem", sim_buf=None,
+                 num_rows=None, profile=False):
+        self.node_distributor = node_distributor
+        self.device = device
+        self.cache_backend = cache_backend
+        self.MPI_comm_manager = MPI_comm_manager
+        self.dim = dim
+        self.sim_buf = sim_buf
+        self.is_simulation = sim_buf is not None
+        self.aggregation_timer = 0.0
+        if not self.is_simulation:
+            raise RuntimeError("sim_buf is None: the NVMe/BaM tier is out of scope here; pass the pinned feature table "
+                               "(the reference's --feat_cpu mode, used by every published script)")
+        if num_rows is None and hasattr(sim_buf, "shape"):
+            num_rows = int(sim_buf.shape[0])
+        sim_ptr = int(sim_buf.data_ptr())
+
+        device_id = MPI_comm_manager.local_rank
+        self.SSD_Controllers = SSD_GNN_SSD_Controllers(num_ssds, page_size, num_elems, ssd_read_offset, device_id, dim,
+                                                       self.is_simulation)
+        self.max_sample_size = batch_size                     # :79-81
+        for i in fan_out:
+            self.max_sample_size *= (int(i) + 1)
+
+        dm = None if node_distributor is None else node_distributor.distribute_manager
+        G = MPI_comm_manager.local_size
+        self.exchange = None
+        if self.cache_backend == "nvshmem":                   # :83-99
+            self.nvshmem_manager = NVSHMEM_Manager(0, MPI_comm_manager.local_rank)
+            self.NVshmem_tensor_manager = NVShmem_Tensor_Manager(self.max_sample_size, dim, G, self.device)
+            self.COALA_GNN_Cache = SSD_GNN_NVSHMEM_Cache(self.SSD_Controllers, dm, MPI_comm_manager.global_rank, G, cache_size,
+                                                         sim_ptr, num_rows=num_rows, profile=profile,
+                                                         max_batch=self.max_sample_size)
+            self.exchange = AllToAllExchange(MPI_comm_manager.nccl_cache_gather, MPI_comm_manager.local_rank, G, dim, self.device)
+            self.COALA_GNN_Cache.attach_exchange(self.exchange)
+        elif self.cache_backend in ("isolated", "nccl"):      # :101-111
+            self.COALA_GNN_Cache = Isolated_Cache(self.SSD_Controllers, dm, MPI_comm_manager.global_rank, G, cache_size,
+                                                  sim_ptr, num_rows=num_rows, profile=profile,
+                                                  max_batch=self.max_sample_size)
+            if self.cache_backend == "nccl":
+                self.exchange = AllToAllExchange(MPI_comm_manager.nccl_cache_gather, MPI_comm_manager.local_rank, G, dim, self.device)
+        else:
+            raise ValueError(f"Unsupported cache backend: {self.cache_backend}")  # the reference prints and returns (:113-115)
+
+    def fetch_feature(self, batch):  # :118-213
+        index = batch[0].to(self.device)
+        if index.dtype != torch.int64:
+            index = index.to(torch.int64)
+        index = index.contiguous()
+        index_size = len(index)
+        index_ptr = index.data_ptr()
+        fetch_start = time.time()
+
+        if self.cache_backend == "nvshmem":
+            return_torch = self.NVshmem_tensor_manager.get_batch_tensor([index_size, self.dim])
+            request_tensor_ptr = self.NVshmem_tensor_manager.get_index_tensor_ptr()
+            self.COALA_GNN_Cache.send_requests(index_ptr, index_size, request_tensor_ptr, self.max_sample_size)
+            self.COALA_GNN_Cache.read_feature(return_torch.data_ptr(), request_tensor_ptr, self.max_sample_size)
+        elif self.cache_backend == "isolated":
+            # torch.empty, not torch.zeros (:138): the kernels write every row, so the 151 MB memset per batch is dropped
+            return_torch = torch.empty([index_size, self.dim], dtype=torch.float, device=self.device)
+            self.COALA_GNN_Cache.read_feature(return_torch.data_ptr(), index_ptr, index_size)
+        elif self.cache_backend == "nccl":
+            return_torch = torch.empty([index_size, self.dim], dtype=torch.float, device=self.device)
+            self.exchange.fetch(self.COALA_GNN_Cache, return_torch.data_ptr(), index_ptr, index_size, self.max_sample_size)
+        else:
+            raise ValueError("Unsupported cache backend for fetch_feature")
+        self._keep_index = index
+        self.aggregation_timer += (time.time() - fetch_start)
+        return (*batch, return_torch)
+
+    def get_cache_data(self, ptr, n_entries=None):
+        self.COALA_GNN_Cache.get_cache_data(ptr, n_entries)
+
+    def print_stats(self):
+        self.COALA_GNN_Cache.print_stats()
+
+    def get_aggregate_time(self):
+        return self.aggregation_timer
+
+    def __del__(self):  # :226-230
+        try:
+            if self.cache_backend == "nvshmem":
+                self.nvshmem_manager.finalize()
+            self.COALA_GNN_Cache.close()
+        except Exception:
+            pass

@@ -1,0 +1,868 @@
+// coala_cache.hip -- MI355X (gfx950 / CDNA4) feature cache: probe + hit gather, deterministic miss ranking, cold fill,
+// owner routing and un-permute.  Hand-written HIP, wave64.  C ABI in include/coala_hip.h.
+//
+// Replaces (paths relative to /root/reference/COALA_GNN_Modules):
+//   isolated_cache.h:335-475 get_data, :145-174 search_ways, :36-50 iso_warp_memcpy, :323-331 read_page_simulation
+//   nvshmem_cache.h:336-480 (same table, distributed set index), seqlock.h (not needed: batch-synchronous design)
+//   cache_kernel.cu:59-77 / :93-111 / :38-57 read kernels, :79-91 split, :113-137 gather, :139-143 stats
+//   ssd_gnn_cache.cuh:84-109,227-360 host front-ends
+//
+// Design (DESIGN.md has the long form).  One call = one batch, three stream-ordered kernels:
+//   K1 probe_gather : a wave takes R rows (4, or 8 for 512-B lines).  One 16-B load per lane fetches the 32 tags of four
+//                     sets at once (16 lanes x 2 keys per set), two ballots find the matching way, hits are copied
+//                     HBM line -> output row with 16-B loads/stores, 4 rows in flight per wave.  Misses are appended to
+//                     a miss list (one wave-aggregated atomic per chunk) and pushed on a per-set chain whose head word is
+//                     tagged with the batch generation (no clearing pass).
+//   K2 rank_assign  : a thread per miss walks its set's chain and counts the misses that precede it in batch order: its
+//                     rank k.  way = (set_cnt + k) % 32 -- the reference's round robin, executed in batch order, for any
+//                     arrival order of the atomics.  Winners (last writer of a way) publish the key; colour counters move.
+//   K3 cold_fill    : a wave per missed row streams it from the cold tier (pinned host over PCIe, or HBM) into the output
+//                     row and, for winners, into the cache line.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/coala_hip.h"
+#include "coala_internal.h"
+
+namespace {
+
+constexpr uint64_t kEmptyKey = 0xFFFFFFFFFFFFFFFFull; // isolated_cache.h:552
+
+struct CacheDev {
+    uint64_t* keys;        // [sets*32]
+    uint32_t* set_cnt;     // [sets]
+    uint32_t* color_meta;  // [sets*32]
+    int32_t* color_counters; // [num_colors+1] or null
+    const int32_t* node_color; // [num_rows] device copy or null
+    float* lines;          // [sets*32*cache_dim]
+    const float* cold;     // [num_rows*dim]
+    uint64_t num_sets;
+    uint64_t num_rows;
+    uint32_t cache_dim;
+    uint32_t dim;
+    uint32_t n_gpus;
+    int32_t gshift;        // log2(n_gpus) if power of two else -1
+    int32_t sshift;        // log2(num_sets) if power of two else -1
+    uint32_t distributed;
+    // per-batch scratch
+    uint32_t* miss_count;  // [2], slot = gen & 1
+    uint64_t* set_head;    // [sets] : (gen << 32) | (miss index + 1)
+    uint32_t* miss_pos;    // [cap] position in the batch
+    uint32_t* miss_next;   // [cap] chain link (miss index + 1, 0 = end)
+    uint32_t* miss_slot;   // [cap] set*32 + way chosen by K2
+    uint32_t* miss_aux;    // [cap] bit0 winner, bit1 rank 0
+    uint32_t* miss_newcnt; // [cap] set_cnt after the batch (valid for rank 0)
+    unsigned long long* stats; // [0] hit [1] miss [2] range errors
+};
+
+__device__ __forceinline__ uint64_t set_of(const CacheDev& c, uint64_t id) {
+    // isolated_cache.h:183-195 ; nvshmem_cache.h:191-196
+    uint64_t k = id;
+    if (c.distributed) {
+        if (c.gshift >= 0) k = id >> c.gshift;
+        else if ((id >> 32) == 0) k = (uint32_t)id / c.n_gpus;
+        else k = id / c.n_gpus;
+    }
+    if (c.sshift >= 0) return k & (c.num_sets - 1);
+    if ((k >> 32) == 0 && (c.num_sets >> 32) == 0) return (uint32_t)k % (uint32_t)c.num_sets;
+    return k % c.num_sets;
+}
+
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int src_lane) {
+    uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)v, src_lane);
+    uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src_lane);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// native clang vectors (not HIP's float4 struct) so the in-flight rows stay in VGPRs
+typedef float vfloat4 __attribute__((ext_vector_type(4)));
+typedef unsigned long long vu64x2 __attribute__((ext_vector_type(2)));
+template <int VEC> struct VecT;
+template <> struct VecT<4> { using type = vfloat4; };
+template <> struct VecT<1> { using type = float; };
+
+// Geometry of the row movers.  VEC = floats per lane access (4 -> 16-B accesses; 1 -> fallback for dim % 4 != 0).
+template <int CD, int VEC>
+struct Geo {
+    static constexpr int UNITS = CD / VEC;                    // accesses per full line
+    static constexpr int LPR = UNITS >= 64 ? 64 : UNITS;      // lanes per row
+    static constexpr int RPP = 64 / LPR;                      // rows per pass (2 for 512-B lines with 16-B accesses)
+    static constexpr int VPL = UNITS / LPR;                   // accesses per lane per row
+    static constexpr int PASSES = (VPL >= 16) ? 1 : 4;        // rows(-pairs) in flight per wave
+    static constexpr int R = RPP * PASSES;                    // rows per chunk
+};
+
+// ---------------------------------------------------------------------------------------------------------- K1
+// Probe R rows, copy the hits, enqueue the misses.
+template <int CD, int VEC>
+__global__ __launch_bounds__(256) void probe_gather_kernel(CacheDev c, const int64_t* __restrict__ idx,
+                                                           float* __restrict__ out, int64_t n, uint32_t gen) {
+    using G = Geo<CD, VEC>;
+    using V = typename VecT<VEC>::type;
+    constexpr int R = G::R;
+    constexpr int TSTEPS = (R + 3) / 4; // tag loads: four sets per wave-wide 16-B load
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t n_chunks = (n + R - 1) / R;
+    const uint32_t nunits = c.dim / VEC; // accesses per output row
+    unsigned long long hits_acc = 0;
+
+    for (int64_t chunk = wave; chunk < n_chunks; chunk += n_waves) {
+        const int64_t base = chunk * R;
+        uint32_t slot[R];       // wave-uniform: set*32 + way for hits
+        uint32_t hitmask = 0;   // bit q: row q hits
+        uint32_t missmask = 0;  // bit q: row q misses (valid, in range, no tag match)
+        uint32_t badmask = 0;   // bit q: id outside [0, num_rows)
+#pragma unroll
+        for (int t = 0; t < TSTEPS; ++t) {
+            const int q_l = t * 4 + (lane >> 4);
+            const int64_t i_l = base + q_l;
+            const bool valid = (q_l < R) && (i_l < n);
+            const uint64_t id = valid ? (uint64_t)idx[i_l] : 0;
+            const bool ok = valid && id < c.num_rows;
+            const uint64_t set = ok ? set_of(c, id) : 0;
+            vu64x2 kk = {kEmptyKey, kEmptyKey};
+            if (ok) kk = *reinterpret_cast<const vu64x2*>(c.keys + set * COALA_WAYS + (lane & 15) * 2);
+            const uint64_t m0 = __ballot(ok && kk.x == id); // even ways
+            const uint64_t m1 = __ballot(ok && kk.y == id); // odd ways
+            const uint64_t okm = __ballot(ok);
+            const uint64_t vm = __ballot(valid);
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const int q = t * 4 + qq;
+                if (q < R) {
+                    const uint32_t a = (uint32_t)(m0 >> (16 * qq)) & 0xFFFFu;
+                    const uint32_t b = (uint32_t)(m1 >> (16 * qq)) & 0xFFFFu;
+                    const uint32_t mm = a | b;
+                    const bool row_valid = (vm >> (16 * qq)) & 1;
+                    const bool row_ok = (okm >> (16 * qq)) & 1;
+                    const uint64_t set_q = readlane64(set, 16 * qq);
+                    uint32_t way = 0;
+                    if (mm) { // lowest matching way wins (isolated_cache.h:165-172)
+                        const int j = __builtin_ctz(mm);
+                        way = 2 * j + (((a >> j) & 1) ? 0 : 1);
+                        hitmask |= 1u << q;
+                    } else if (row_ok) {
+                        missmask |= 1u << q;
+                    } else if (row_valid) {
+                        badmask |= 1u << q;
+                    }
+                    slot[q] = (uint32_t)(set_q * COALA_WAYS) + way;
+                }
+            }
+        }
+
+        // ---- hits: HBM line -> output row, PASSES row(-pair)s in flight
+        V val[G::PASSES][G::VPL];
+        const int sub = (G::RPP == 2) ? (lane >> 5) : 0;
+        const int l_in = lane & (G::LPR - 1);
+#pragma unroll
+        for (int p = 0; p < G::PASSES; ++p) {
+            const int q = p * G::RPP + sub;
+            const uint32_t s = (G::RPP == 2) ? (sub ? slot[p * G::RPP + (G::RPP - 1)] : slot[p * G::RPP]) : slot[p];
+            const bool h = (hitmask >> q) & 1;
+            const V* src = reinterpret_cast<const V*>(c.lines + (uint64_t)s * CD);
+#pragma unroll
+            for (int v = 0; v < G::VPL; ++v) {
+                const uint32_t u = v * G::LPR + l_in;
+                if (h && u < nunits) val[p][v] = src[u];
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < G::PASSES; ++p) {
+            const int q = p * G::RPP + sub;
+            const bool h = (hitmask >> q) & 1;
+            const bool bad = (badmask >> q) & 1;
+            V* dst = reinterpret_cast<V*>(out + (base + q) * (int64_t)c.dim);
+#pragma unroll
+            for (int v = 0; v < G::VPL; ++v) {
+                const uint32_t u = v * G::LPR + l_in;
+                if (u < nunits) {
+                    if (h) dst[u] = val[p][v];
+                    else if (bad) dst[u] = V(0.0f); // rejected id: zero row
+                }
+            }
+        }
+        hits_acc += __builtin_popcount(hitmask);
+
+        // ---- misses: wave-aggregated append + per-set chain push
+        if (missmask) {
+            uint32_t basem = 0;
+            if (lane == 0) basem = atomicAdd(c.miss_count + (gen & 1), (uint32_t)__builtin_popcount(missmask));
+            basem = __builtin_amdgcn_readfirstlane(basem);
+            if (lane < R && ((missmask >> lane) & 1)) {
+                const int64_t i_m = base + lane;
+                const uint64_t id = (uint64_t)idx[i_m];
+                const uint64_t set = set_of(c, id);
+                const uint32_t m = basem + __builtin_popcount(missmask & ((1u << lane) - 1));
+                const unsigned long long tag = ((unsigned long long)gen << 32) | (unsigned long long)(m + 1);
+                const unsigned long long prev = atomicExch(reinterpret_cast<unsigned long long*>(c.set_head + set), tag);
+                c.miss_pos[m] = (uint32_t)i_m;
+                c.miss_next[m] = ((uint32_t)(prev >> 32) == gen) ? (uint32_t)prev : 0u;
+            }
+        }
+        if (badmask && lane == 0) atomicAdd(c.stats + 2, (unsigned long long)__builtin_popcount(badmask));
+    }
+    if (lane == 0 && hits_acc) atomicAdd(c.stats + 0, hits_acc);
+}
+
+// ---------------------------------------------------------------------------------------------------------- K2
+// Deterministic round-robin victim choice: rank of a miss = number of misses of the same set that precede it in the
+// batch.  (isolated_cache.h:197-210 executed in batch order.)
+__global__ __launch_bounds__(256) void rank_assign_kernel(CacheDev c, const int64_t* __restrict__ idx, uint32_t gen) {
+    const uint32_t M = c.miss_count[gen & 1];
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t t0 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t0 == 0 && M) atomicAdd(c.stats + 1, (unsigned long long)M);
+    for (uint32_t m = t0; m < M; m += stride) {
+        const uint32_t pos = c.miss_pos[m];
+        const uint64_t id = (uint64_t)idx[pos];
+        const uint64_t set = set_of(c, id);
+        uint32_t cur = (uint32_t)c.set_head[set]; // tagged with this generation by construction
+        uint32_t total = 0, rank = 0;
+        while (cur) {
+            const uint32_t mm = cur - 1;
+            const uint32_t p2 = c.miss_pos[mm];
+            ++total;
+            rank += (p2 < pos) ? 1u : 0u;
+            cur = c.miss_next[mm];
+        }
+        const uint32_t cnt0 = c.set_cnt[set];
+        const uint32_t way = (cnt0 + rank) & (COALA_WAYS - 1);
+        const uint32_t slot = (uint32_t)(set * COALA_WAYS) + way;
+        const bool winner = rank + COALA_WAYS >= total; // nobody later in the batch lands on this way
+        const bool first = rank < COALA_WAYS;            // evicts the pre-batch occupant
+        if (c.color_counters) {
+            if (first) atomicSub(c.color_counters + c.color_meta[slot], 1);      // isolated_cache.h:427-429
+            if (winner) atomicAdd(c.color_counters + c.node_color[id], 1);       // isolated_cache.h:437-441
+        }
+        if (winner) c.keys[slot] = id;                                           // isolated_cache.h:434
+        c.miss_slot[m] = slot;
+        c.miss_aux[m] = (winner ? 1u : 0u) | (rank == 0 ? 2u : 0u);
+        c.miss_newcnt[m] = cnt0 + total;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------- K3
+// Cold tier -> output row (+ cache line for winners).  isolated_cache.h:323-331,449-465.
+template <int CD, int VEC>
+__global__ __launch_bounds__(256) void cold_fill_kernel(CacheDev c, const int64_t* __restrict__ idx, float* __restrict__ out,
+                                                        uint32_t gen) {
+    using G = Geo<CD, VEC>;
+    using V = typename VecT<VEC>::type;
+    constexpr int R = G::R;
+    const int lane = threadIdx.x & 63;
+    const uint32_t M = c.miss_count[gen & 1];
+    if (blockIdx.x == 0 && threadIdx.x == 0) c.miss_count[(gen + 1) & 1] = 0; // next batch's counter
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t n_chunks = ((int64_t)M + R - 1) / R;
+    const uint32_t nunits = c.dim / VEC;
+    const int sub = (G::RPP == 2) ? (lane >> 5) : 0;
+    const int l_in = lane & (G::LPR - 1);
+
+    for (int64_t chunk = wave; chunk < n_chunks; chunk += n_waves) {
+        const int64_t base = chunk * R;
+        V val[G::PASSES][G::VPL];
+        uint32_t pos[G::PASSES], slot_[G::PASSES], aux[G::PASSES], ncnt[G::PASSES];
+        uint64_t id[G::PASSES];
+        bool live[G::PASSES];
+#pragma unroll
+        for (int p = 0; p < G::PASSES; ++p) {
+            const int64_t m = base + p * G::RPP + sub;
+            live[p] = m < (int64_t)M;
+            pos[p] = slot_[p] = aux[p] = ncnt[p] = 0;
+            id[p] = 0;
+            if (live[p]) {
+                pos[p] = c.miss_pos[m];
+                slot_[p] = c.miss_slot[m];
+                aux[p] = c.miss_aux[m];
+                ncnt[p] = c.miss_newcnt[m];
+                id[p] = (uint64_t)idx[pos[p]];
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < G::PASSES; ++p) {
+            const V* src = reinterpret_cast<const V*>(c.cold + id[p] * (uint64_t)c.dim); // host stride = dim
+#pragma unroll
+            for (int v = 0; v < G::VPL; ++v) {
+                const uint32_t u = v * G::LPR + l_in;
+                if (live[p] && u < nunits) val[p][v] = src[u];
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < G::PASSES; ++p) {
+            V* dst = reinterpret_cast<V*>(out + (uint64_t)pos[p] * c.dim);
+            V* line = reinterpret_cast<V*>(c.lines + (uint64_t)slot_[p] * CD);
+            const bool winner = aux[p] & 1u;
+#pragma unroll
+            for (int v = 0; v < G::VPL; ++v) {
+                const uint32_t u = v * G::LPR + l_in;
+                if (live[p] && u < nunits) {
+                    dst[u] = val[p][v];
+                    if (winner) line[u] = val[p][v];
+                }
+            }
+            if (live[p] && l_in == 0) {
+                if (winner && c.node_color) c.color_meta[slot_[p]] = (uint32_t)c.node_color[id[p]]; // isolated_cache.h:438
+                if (aux[p] & 2u) c.set_cnt[slot_[p] / COALA_WAYS] = ncnt[p];                         // isolated_cache.h:203
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------- scatter
+// out[map[r], :] = src[r, :]   (cache_kernel.cu:113-137)
+template <int CD, int VEC>
+__global__ __launch_bounds__(256) void scatter_rows_kernel(float* __restrict__ out, const float* __restrict__ src,
+                                                           const int64_t* __restrict__ map, int64_t n, uint32_t dim) {
+    using G = Geo<CD, VEC>;
+    using V = typename VecT<VEC>::type;
+    constexpr int R = G::R;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t n_chunks = (n + R - 1) / R;
+    const uint32_t nunits = dim / VEC;
+    const int sub = (G::RPP == 2) ? (lane >> 5) : 0;
+    const int l_in = lane & (G::LPR - 1);
+    for (int64_t chunk = wave; chunk < n_chunks; chunk += n_waves) {
+        const int64_t base = chunk * R;
+        V val[G::PASSES][G::VPL];
+        int64_t d[G::PASSES];
+#pragma unroll
+        for (int p = 0; p < G::PASSES; ++p) {
+            const int64_t r = base + p * G::RPP + sub;
+            d[p] = (r < n) ? map[r] : -1;
+            const V* s = reinterpret_cast<const V*>(src + r * (int64_t)dim);
+#pragma unroll
+            for (int v = 0; v < G::VPL; ++v) {
+                const uint32_t u = v * G::LPR + l_in;
+                if (d[p] >= 0 && u < nunits) val[p][v] = s[u];
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < G::PASSES; ++p) {
+            V* t = reinterpret_cast<V*>(out + d[p] * (int64_t)dim);
+#pragma unroll
+            for (int v = 0; v < G::VPL; ++v) {
+                const uint32_t u = v * G::LPR + l_in;
+                if (d[p] >= 0 && u < nunits) t[u] = val[p][v];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------- route
+// Stable bucketing by owner = id % n_parts (cache_kernel.cu:79-91, :4-17) with wave ballots + prefix sums instead of
+// atomics, so the slot order inside a bucket is the batch order on every run.
+constexpr int kRouteItems = 4;            // ids per lane
+constexpr int kRouteTile = 64 * kRouteItems; // ids per wave
+
+__device__ __forceinline__ uint32_t owner_of(uint64_t id, uint32_t n_parts, int pshift) {
+    if (pshift >= 0) return (uint32_t)id & (n_parts - 1);
+    if ((id >> 32) == 0) return (uint32_t)id % n_parts;
+    return (uint32_t)(id % n_parts);
+}
+
+__global__ __launch_bounds__(256) void route_count_kernel(const int64_t* __restrict__ idx, int64_t n, uint32_t n_parts,
+                                                          int pshift, uint32_t* __restrict__ wave_counts, int64_t n_tiles) {
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (tile >= n_tiles) return;
+    uint32_t mine = 0; // lane g accumulates the count of owner g
+    for (int j = 0; j < kRouteItems; ++j) {
+        const int64_t i = tile * kRouteTile + j * 64 + lane;
+        const bool valid = i < n;
+        const uint32_t o = valid ? owner_of((uint64_t)idx[i], n_parts, pshift) : 0xFFFFFFFFu;
+        for (uint32_t g = 0; g < n_parts; ++g) {
+            const uint64_t mask = __ballot(o == g);
+            if ((uint32_t)lane == g) mine += (uint32_t)__builtin_popcountll(mask);
+        }
+    }
+    if ((uint32_t)lane < n_parts) wave_counts[tile * n_parts + lane] = mine;
+}
+
+// One block: exclusive scan of wave_counts over tiles for every owner, bucket totals and bucket bases.
+__global__ __launch_bounds__(1024) void route_scan_kernel(uint32_t* __restrict__ wave_counts, int64_t n_tiles, uint32_t n_parts,
+                                                          int64_t bucket_stride, int64_t* __restrict__ counts_out,
+                                                          int64_t* __restrict__ offsets_out, int64_t* __restrict__ bases) {
+    __shared__ uint32_t part[1024];
+    __shared__ int64_t totals[64];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t nthr = blockDim.x;
+    for (uint32_t g = 0; g < n_parts; ++g) {
+        const int64_t per = (n_tiles + nthr - 1) / nthr;
+        const int64_t lo = (int64_t)tid * per;
+        const int64_t hi = lo + per < n_tiles ? lo + per : n_tiles;
+        uint32_t s = 0;
+        for (int64_t t = lo; t < hi; ++t) s += wave_counts[t * n_parts + g];
+        part[tid] = s;
+        __syncthreads();
+        // Hillis-Steele inclusive scan over the block
+        for (uint32_t off = 1; off < nthr; off <<= 1) {
+            uint32_t v = (tid >= off) ? part[tid - off] : 0;
+            __syncthreads();
+            part[tid] += v;
+            __syncthreads();
+        }
+        uint32_t run = part[tid] - s; // exclusive prefix of this thread's segment
+        for (int64_t t = lo; t < hi; ++t) {
+            const uint32_t cnt = wave_counts[t * n_parts + g];
+            wave_counts[t * n_parts + g] = run;
+            run += cnt;
+        }
+        if (tid == nthr - 1) totals[g] = part[tid];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        int64_t acc = 0;
+        for (uint32_t g = 0; g < n_parts; ++g) {
+            counts_out[g] = totals[g];
+            const int64_t b = bucket_stride > 0 ? (int64_t)g * bucket_stride : acc;
+            bases[g] = b;
+            if (offsets_out) offsets_out[g] = b;
+            acc += totals[g];
+        }
+        if (offsets_out) offsets_out[n_parts] = bucket_stride > 0 ? (int64_t)n_parts * bucket_stride : acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void route_scatter_kernel(const int64_t* __restrict__ idx, int64_t n, uint32_t n_parts,
+                                                            int pshift, const uint32_t* __restrict__ wave_offsets,
+                                                            const int64_t* __restrict__ bases, int64_t* __restrict__ node_out,
+                                                            int64_t* __restrict__ map_out, int64_t n_tiles) {
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (tile >= n_tiles) return;
+    int64_t off = 0; // lane g: next free slot of bucket g for this wave
+    if ((uint32_t)lane < n_parts) off = bases[lane] + (int64_t)wave_offsets[tile * n_parts + lane];
+    for (int j = 0; j < kRouteItems; ++j) {
+        const int64_t i = tile * kRouteTile + j * 64 + lane;
+        const bool valid = i < n;
+        const int64_t id = valid ? idx[i] : 0;
+        const uint32_t o = valid ? owner_of((uint64_t)id, n_parts, pshift) : 0xFFFFFFFFu;
+        int64_t dest = -1;
+        for (uint32_t g = 0; g < n_parts; ++g) {
+            const uint64_t mask = __ballot(o == g);
+            const int64_t bg = __shfl(off, (int)g);
+            if (o == g) dest = bg + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+            if ((uint32_t)lane == g) off += __builtin_popcountll(mask);
+        }
+        if (valid) {
+            node_out[dest] = id;
+            map_out[dest] = i;
+        }
+    }
+}
+
+} // namespace
+
+// ============================================================================================================ host
+
+struct coala_cache {
+    coala_cache_config_t cfg;
+    CacheDev d;
+    uint64_t cap = 0;           // scratch capacity (rows)
+    uint32_t gen = 0;
+    int32_t* node_color_dev = nullptr;
+    // route scratch
+    uint32_t* wave_counts = nullptr;
+    uint64_t wave_counts_cap = 0;
+    int64_t* route_bases = nullptr;
+    // profiling
+    struct EvPair { hipEvent_t a, b; int kind; uint64_t rows; };
+    std::vector<EvPair> ev_live;
+    std::vector<hipEvent_t> ev_pool;
+    coala_cache_profile_t prof{};
+    uint64_t table_bytes = 0;
+    uint64_t cum_hit = 0, cum_miss = 0;   // totals folded in whenever coala_cache_stats resets the device counters
+    uint64_t prof_hit0 = 0, prof_miss0 = 0; // totals at the last profile reset
+};
+
+namespace {
+
+#define fail coala_fail_
+#define HIPCHK COALA_HIPCHK
+
+int ilog2_exact(uint64_t v) {
+    if (v == 0 || (v & (v - 1))) return -1;
+    int s = 0;
+    while ((1ull << s) != v) ++s;
+    return s;
+}
+
+int ensure_scratch(coala_cache* h, uint64_t n, hipStream_t s) {
+    if (n <= h->cap) return COALA_OK;
+    HIPCHK(hipStreamSynchronize(s));
+    uint64_t cap = h->cap ? h->cap : 1024;
+    while (cap < n) cap *= 2;
+    uint32_t** arrs[] = {&h->d.miss_pos, &h->d.miss_next, &h->d.miss_slot, &h->d.miss_aux, &h->d.miss_newcnt};
+    for (auto a : arrs) {
+        if (*a) HIPCHK(hipFree(*a));
+        *a = nullptr;
+        HIPCHK(hipMalloc((void**)a, cap * sizeof(uint32_t)));
+    }
+    h->cap = cap;
+    return COALA_OK;
+}
+
+hipEvent_t take_event(coala_cache* h) {
+    if (!h->ev_pool.empty()) {
+        hipEvent_t e = h->ev_pool.back();
+        h->ev_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+void drain_events(coala_cache* h) {
+    for (auto& p : h->ev_live) {
+        float ms = 0.f;
+        if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            if (p.kind == 0) { h->prof.gather_ms += ms; h->prof.gather_launches++; h->prof.gather_rows += p.rows; }
+            else if (p.kind == 1) { h->prof.rank_ms += ms; }
+            else { h->prof.fill_ms += ms; h->prof.fill_launches++; }
+        }
+        h->ev_pool.push_back(p.a);
+        h->ev_pool.push_back(p.b);
+    }
+    h->ev_live.clear();
+}
+
+struct ProfScope {
+    coala_cache* h; hipStream_t s; int kind; uint64_t rows; hipEvent_t a = nullptr, b = nullptr; bool on;
+    ProfScope(coala_cache* h_, hipStream_t s_, int kind_, uint64_t rows_) : h(h_), s(s_), kind(kind_), rows(rows_) {
+        on = (h->cfg.flags & COALA_FLAG_PROFILE) != 0;
+        if (on) {
+            if (h->ev_live.size() >= 8192) drain_events(h);
+            a = take_event(h); b = take_event(h);
+            on = a && b;
+            if (on) (void)hipEventRecord(a, s);
+        }
+    }
+    ~ProfScope() {
+        if (on) {
+            (void)hipEventRecord(b, s);
+            h->ev_live.push_back({a, b, kind, rows});
+        }
+    }
+};
+
+template <typename F>
+int dispatch_geo(uint32_t cache_dim, bool vec4, F&& f) {
+    switch (cache_dim) {
+        case 128: return vec4 ? f(Geo<128, 4>{}) : f(Geo<128, 1>{});
+        case 256: return vec4 ? f(Geo<256, 4>{}) : f(Geo<256, 1>{});
+        case 512: return vec4 ? f(Geo<512, 4>{}) : f(Geo<512, 1>{});
+        case 1024: return vec4 ? f(Geo<1024, 4>{}) : f(Geo<1024, 1>{});
+    }
+    return fail(COALA_EINVAL, "unsupported cache_dim %u", cache_dim);
+}
+
+template <int CD, int VEC> constexpr int geo_cd(Geo<CD, VEC>) { return CD; }
+template <int CD, int VEC> constexpr int geo_vec(Geo<CD, VEC>) { return VEC; }
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+int grid_for(int64_t chunks, int waves_per_block, int max_blocks) {
+    int64_t blocks = (chunks + waves_per_block - 1) / waves_per_block;
+    if (blocks < 1) blocks = 1;
+    if (blocks > max_blocks) blocks = max_blocks;
+    return (int)blocks;
+}
+
+} // namespace
+
+extern "C" {
+
+int coala_cache_dim(int dim) { // ssd_gnn_cache.cuh:34-44
+    if (dim <= 0) return fail(COALA_EINVAL, "dim must be positive");
+    if (dim <= 128) return 128;
+    if (dim <= 256) return 256;
+    if (dim <= 512) return 512;
+    if (dim <= 1024) return 1024;
+    return fail(COALA_EINVAL, "Only Feature Embedding Size less than 8KB is supported");
+}
+
+uint64_t coala_cache_num_sets(uint64_t cache_mb, int cache_dim) { // ssd_gnn_cache.cuh:96-97
+    if (cache_dim <= 0) return 0;
+    const uint64_t page = (uint64_t)cache_dim * sizeof(float);
+    return (cache_mb * 1024ull * 1024ull / page) / COALA_WAYS;
+}
+
+int coala_cache_create(const coala_cache_config_t* cfg, coala_cache_t** out) {
+    if (!cfg || !out) return fail(COALA_EINVAL, "null argument");
+    *out = nullptr;
+    const int cd = coala_cache_dim(cfg->dim);
+    if (cd < 0) return cd;
+    if (!cfg->cold_table) return fail(COALA_EINVAL, "cold_table is null (the NVMe/BaM tier is out of scope: pass the pinned feature table)");
+    if (cfg->n_gpus < 1 || cfg->rank < 0 || cfg->rank >= cfg->n_gpus) return fail(COALA_EINVAL, "bad rank/n_gpus");
+    const uint64_t sets = coala_cache_num_sets(cfg->cache_mb, cd);
+    if (sets == 0) return fail(COALA_EINVAL, "cache_mb=%llu gives zero sets", (unsigned long long)cfg->cache_mb);
+    if (sets * COALA_WAYS > 0xFFFFFFFFull) return fail(COALA_EINVAL, "cache too large: more than 2^32 lines");
+    if (cfg->node_color && cfg->num_colors < 0) return fail(COALA_EINVAL, "num_colors < 0");
+    HIPCHK(hipSetDevice(cfg->device));
+    coala_cache* h = new (std::nothrow) coala_cache();
+    if (!h) return fail(COALA_ENOMEM, "out of host memory");
+    h->cfg = *cfg;
+    CacheDev& d = h->d;
+    memset(&d, 0, sizeof(d));
+    const uint64_t slots = sets * COALA_WAYS;
+    d.num_sets = sets;
+    d.num_rows = cfg->num_rows;
+    d.cache_dim = (uint32_t)cd;
+    d.dim = (uint32_t)cfg->dim;
+    d.n_gpus = (uint32_t)cfg->n_gpus;
+    d.gshift = ilog2_exact((uint64_t)cfg->n_gpus);
+    d.sshift = ilog2_exact(sets);
+    d.distributed = (cfg->flags & COALA_FLAG_DISTRIBUTED) ? 1u : 0u;
+    d.cold = cfg->cold_table;
+    int rc = COALA_OK;
+    auto alloc = [&](void** p, uint64_t bytes) -> int {
+        hipError_t e = hipMalloc(p, bytes);
+        if (e != hipSuccess) return fail(COALA_ENOMEM, "hipMalloc(%llu) failed: %s", (unsigned long long)bytes, hipGetErrorString(e));
+        h->table_bytes += bytes;
+        return COALA_OK;
+    };
+    do {
+        if ((rc = alloc((void**)&d.keys, slots * 8))) break;
+        if ((rc = alloc((void**)&d.set_cnt, sets * 4))) break;
+        if ((rc = alloc((void**)&d.color_meta, slots * 4))) break;
+        if ((rc = alloc((void**)&d.set_head, sets * 8))) break;
+        if ((rc = alloc((void**)&d.miss_count, 2 * 4))) break;
+        if ((rc = alloc((void**)&d.stats, 3 * 8))) break;
+        if ((rc = alloc((void**)&d.lines, slots * (uint64_t)cd * 4))) break;
+        if ((rc = alloc((void**)&h->route_bases, 65 * 8))) break;
+        if (hipMemset(d.keys, 0xFF, slots * 8) != hipSuccess || hipMemset(d.set_cnt, 0, sets * 4) != hipSuccess ||
+            hipMemset(d.color_meta, 0, slots * 4) != hipSuccess || hipMemset(d.set_head, 0, sets * 8) != hipSuccess ||
+            hipMemset(d.miss_count, 0, 8) != hipSuccess || hipMemset(d.stats, 0, 24) != hipSuccess) {
+            rc = fail(COALA_EHIP, "hipMemset failed");
+            break;
+        }
+        if (cfg->node_color) {
+            if ((rc = alloc((void**)&d.color_counters, ((uint64_t)cfg->num_colors + 1) * 4))) break;
+            if (hipMemset(d.color_counters, 0, ((uint64_t)cfg->num_colors + 1) * 4) != hipSuccess) { rc = fail(COALA_EHIP, "hipMemset failed"); break; }
+            if ((rc = alloc((void**)&h->node_color_dev, cfg->num_rows * 4))) break;
+            // narrow int64 colours to int32 on the host in chunks, validating the range
+            const uint64_t chunk = 1ull << 22;
+            std::vector<int32_t> tmp((size_t)(cfg->num_rows < chunk ? cfg->num_rows : chunk));
+            for (uint64_t off = 0; off < cfg->num_rows && rc == COALA_OK; off += chunk) {
+                const uint64_t cnt = cfg->num_rows - off < chunk ? cfg->num_rows - off : chunk;
+                for (uint64_t k = 0; k < cnt; ++k) {
+                    const int64_t col = cfg->node_color[off + k];
+                    if (col < 0 || col > cfg->num_colors) { rc = fail(COALA_EINVAL, "node_color[%llu]=%lld outside [0,%d]", (unsigned long long)(off + k), (long long)col, cfg->num_colors); break; }
+                    tmp[k] = (int32_t)col;
+                }
+                if (rc == COALA_OK && hipMemcpy(h->node_color_dev + off, tmp.data(), cnt * 4, hipMemcpyHostToDevice) != hipSuccess)
+                    rc = fail(COALA_EHIP, "colour upload failed");
+            }
+            if (rc) break;
+            d.node_color = h->node_color_dev;
+        }
+        h->gen = 0;
+        if (cfg->max_batch) rc = ensure_scratch(h, cfg->max_batch, nullptr);
+    } while (0);
+    if (rc == COALA_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(COALA_EHIP, "device sync failed after create");
+    if (rc != COALA_OK) {
+        coala_cache_destroy(h); // does not touch the recorded error
+        return rc;
+    }
+    *out = h;
+    return COALA_OK;
+}
+
+int coala_cache_destroy(coala_cache_t* h) {
+    if (!h) return COALA_OK;
+    (void)hipSetDevice(h->cfg.device);
+    (void)hipDeviceSynchronize();
+    drain_events(h);
+    for (auto e : h->ev_pool) (void)hipEventDestroy(e);
+    CacheDev& d = h->d;
+    void* ptrs[] = {d.keys, d.set_cnt, d.color_meta, d.set_head, d.miss_count, d.stats, d.lines, d.color_counters,
+                    h->node_color_dev, d.miss_pos, d.miss_next, d.miss_slot, d.miss_aux, d.miss_newcnt,
+                    h->wave_counts, h->route_bases};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    delete h;
+    return COALA_OK;
+}
+
+int coala_cache_geometry(const coala_cache_t* h, coala_cache_geometry_t* out) {
+    if (!h || !out) return fail(COALA_EINVAL, "null argument");
+    out->num_sets = h->d.num_sets;
+    out->num_ways = COALA_WAYS;
+    out->cache_dim = h->d.cache_dim;
+    out->line_bytes = (uint64_t)h->d.cache_dim * 4;
+    out->table_bytes = h->table_bytes;
+    return COALA_OK;
+}
+
+static int read_feature_impl(coala_cache_t* h, float* out, const int64_t* idx, int64_t n, void* stream, bool force_dist) {
+    if (!h) return fail(COALA_EINVAL, "null handle");
+    if (n < 0 || n > 0x7FFFFFFFll) return fail(COALA_EINVAL, "n=%lld out of range", (long long)n);
+    if (n == 0) return COALA_OK;
+    if (!out || !idx) return fail(COALA_EINVAL, "null buffer");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    int rc = ensure_scratch(h, (uint64_t)n, s);
+    if (rc) return rc;
+    if (++h->gen == 0) { // generation wrapped: clear the chain heads once
+        HIPCHK(hipMemsetAsync(h->d.set_head, 0, h->d.num_sets * 8, s));
+        h->gen = 1;
+    }
+    const uint32_t gen = h->gen;
+    const bool vec4 = (h->d.dim % 4 == 0) && aligned16(out) && aligned16(h->d.cold);
+    CacheDev d = h->d;
+    if (force_dist) d.distributed = 1u;
+    rc = dispatch_geo(d.cache_dim, vec4, [&](auto geo) -> int {
+        constexpr int CD = geo_cd(geo);
+        constexpr int VEC = geo_vec(geo);
+        using G = Geo<CD, VEC>;
+        const int64_t chunks = (n + G::R - 1) / G::R;
+        {
+            ProfScope ps(h, s, 0, (uint64_t)n);
+            hipLaunchKernelGGL((probe_gather_kernel<CD, VEC>), dim3(grid_for(chunks, 4, 256 * 16)), dim3(256), 0, s, d, idx, out, n, gen);
+        }
+        {
+            ProfScope ps(h, s, 1, 0);
+            hipLaunchKernelGGL(rank_assign_kernel, dim3(grid_for((n + 255) / 256, 1, 1024)), dim3(256), 0, s, d, idx, gen);
+        }
+        {
+            ProfScope ps(h, s, 2, 0);
+            hipLaunchKernelGGL((cold_fill_kernel<CD, VEC>), dim3(grid_for(chunks, 4, 256 * 8)), dim3(256), 0, s, d, idx, out, gen);
+        }
+        return COALA_OK;
+    });
+    if (rc) return rc;
+    HIPCHK(hipGetLastError());
+    if (h->cfg.flags & COALA_FLAG_SYNC) HIPCHK(hipStreamSynchronize(s));
+    return COALA_OK;
+}
+
+int coala_cache_read_feature(coala_cache_t* h, float* out, const int64_t* idx, int64_t n, void* stream) {
+    return read_feature_impl(h, out, idx, n, stream, false);
+}
+
+int coala_cache_serve(coala_cache_t* h, float* out, const int64_t* ids, int64_t n, void* stream) {
+    return read_feature_impl(h, out, ids, n, stream, true);
+}
+
+int coala_cache_route(coala_cache_t* h, const int64_t* idx, int64_t n, int n_parts, int64_t bucket_stride,
+                      int64_t* node_out, int64_t* map_out, int64_t* counts_out, int64_t* offsets_out, void* stream) {
+    if (!h) return fail(COALA_EINVAL, "null handle");
+    if (n < 0 || n_parts < 1 || n_parts > 64) return fail(COALA_EINVAL, "bad n or n_parts (1..64)");
+    if (!node_out || !map_out || !counts_out || (n > 0 && !idx)) return fail(COALA_EINVAL, "null buffer");
+    if (bucket_stride < 0) return fail(COALA_EINVAL, "negative bucket_stride");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const int64_t n_tiles = (n + kRouteTile - 1) / kRouteTile;
+    const uint64_t need = (uint64_t)(n_tiles > 0 ? n_tiles : 1) * (uint64_t)n_parts;
+    if (need > h->wave_counts_cap) {
+        HIPCHK(hipStreamSynchronize(s));
+        if (h->wave_counts) HIPCHK(hipFree(h->wave_counts));
+        h->wave_counts = nullptr;
+        uint64_t cap = h->wave_counts_cap ? h->wave_counts_cap : 4096;
+        while (cap < need) cap *= 2;
+        HIPCHK(hipMalloc((void**)&h->wave_counts, cap * 4));
+        h->wave_counts_cap = cap;
+    }
+    const int pshift = ilog2_exact((uint64_t)n_parts);
+    const int blocks = (int)((n_tiles + 3) / 4);
+    if (n_tiles > 0)
+        hipLaunchKernelGGL(route_count_kernel, dim3(blocks), dim3(256), 0, s, idx, n, (uint32_t)n_parts, pshift, h->wave_counts, n_tiles);
+    hipLaunchKernelGGL(route_scan_kernel, dim3(1), dim3(1024), 0, s, h->wave_counts, n_tiles, (uint32_t)n_parts, bucket_stride,
+                       counts_out, offsets_out, h->route_bases);
+    if (n_tiles > 0)
+        hipLaunchKernelGGL(route_scatter_kernel, dim3(blocks), dim3(256), 0, s, idx, n, (uint32_t)n_parts, pshift, h->wave_counts,
+                           h->route_bases, node_out, map_out, n_tiles);
+    HIPCHK(hipGetLastError());
+    if (h->cfg.flags & COALA_FLAG_SYNC) HIPCHK(hipStreamSynchronize(s));
+    return COALA_OK;
+}
+
+int coala_cache_scatter(coala_cache_t* h, float* out, const float* src, const int64_t* map, int64_t n, void* stream) {
+    if (!h) return fail(COALA_EINVAL, "null handle");
+    if (n < 0) return fail(COALA_EINVAL, "negative n");
+    if (n == 0) return COALA_OK;
+    if (!out || !src || !map) return fail(COALA_EINVAL, "null buffer");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const uint32_t dim = h->d.dim;
+    const bool vec4 = (dim % 4 == 0) && aligned16(out) && aligned16(src);
+    int rc = dispatch_geo(h->d.cache_dim, vec4, [&](auto geo) -> int {
+        constexpr int CD = geo_cd(geo);
+        constexpr int VEC = geo_vec(geo);
+        using G = Geo<CD, VEC>;
+        const int64_t chunks = (n + G::R - 1) / G::R;
+        hipLaunchKernelGGL((scatter_rows_kernel<CD, VEC>), dim3(grid_for(chunks, 4, 256 * 16)), dim3(256), 0, s, out, src, map, n, dim);
+        return COALA_OK;
+    });
+    if (rc) return rc;
+    HIPCHK(hipGetLastError());
+    if (h->cfg.flags & COALA_FLAG_SYNC) HIPCHK(hipStreamSynchronize(s));
+    return COALA_OK;
+}
+
+int coala_cache_color_counts(coala_cache_t* h, int32_t* dst, int32_t n_entries, void* stream) {
+    if (!h || !dst) return fail(COALA_EINVAL, "null argument");
+    if (n_entries < 0 || n_entries > h->cfg.num_colors + 1) return fail(COALA_EINVAL, "n_entries=%d exceeds num_colors+1=%d", n_entries, h->cfg.num_colors + 1);
+    if (!h->d.color_counters) { memset(dst, 0, (size_t)n_entries * 4); return COALA_OK; }
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipMemcpyAsync(dst, h->d.color_counters, (size_t)n_entries * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return COALA_OK;
+}
+
+int coala_cache_stats(coala_cache_t* h, uint64_t* hit, uint64_t* miss, uint64_t* range_errors, int reset, void* stream) {
+    if (!h) return fail(COALA_EINVAL, "null handle");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    unsigned long long v[3];
+    HIPCHK(hipMemcpyAsync(v, h->d.stats, sizeof(v), hipMemcpyDeviceToHost, s));
+    if (reset) HIPCHK(hipMemsetAsync(h->d.stats, 0, sizeof(v), s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (reset) { h->cum_hit += v[0]; h->cum_miss += v[1]; }
+    if (hit) *hit = v[0];
+    if (miss) *miss = v[1];
+    if (range_errors) *range_errors = v[2];
+    return COALA_OK;
+}
+
+int coala_cache_dump(coala_cache_t* h, uint64_t* keys, uint32_t* set_cnt, uint32_t* color_meta, void* stream) {
+    if (!h) return fail(COALA_EINVAL, "null handle");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const uint64_t slots = h->d.num_sets * COALA_WAYS;
+    HIPCHK(hipStreamSynchronize(s));
+    if (keys) HIPCHK(hipMemcpy(keys, h->d.keys, slots * 8, hipMemcpyDeviceToHost));
+    if (set_cnt) HIPCHK(hipMemcpy(set_cnt, h->d.set_cnt, h->d.num_sets * 4, hipMemcpyDeviceToHost));
+    if (color_meta) HIPCHK(hipMemcpy(color_meta, h->d.color_meta, slots * 4, hipMemcpyDeviceToHost));
+    return COALA_OK;
+}
+
+int coala_cache_profile(coala_cache_t* h, coala_cache_profile_t* out, int reset) {
+    if (!h || !out) return fail(COALA_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    drain_events(h);
+    unsigned long long v[3];
+    HIPCHK(hipMemcpy(v, h->d.stats, sizeof(v), hipMemcpyDeviceToHost));
+    const uint64_t th = h->cum_hit + v[0], tm = h->cum_miss + v[1];
+    h->prof.gather_hits = th - h->prof_hit0;
+    h->prof.fill_rows = tm - h->prof_miss0;
+    *out = h->prof;
+    if (reset) { h->prof = coala_cache_profile_t{}; h->prof_hit0 = th; h->prof_miss0 = tm; }
+    return COALA_OK;
+}
+
+} // extern "C"

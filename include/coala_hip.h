@@ -1,0 +1,184 @@
+/*
+ * coala_hip.h -- C ABI of libcoala_hip.so: the MI355X (gfx950) feature-cache / minibatch-assembly path.
+ *
+ * This is the drop-in boundary for the hot path of jeongminpark417/COALA-GNN.  Every entry point names the
+ * reference interface it replaces (paths relative to /root/reference).  Plain pointers and sizes only: no torch,
+ * pybind or C++ types cross this boundary.  All functions return 0 on success or a negative COALA_E* code;
+ * coala_last_error() returns a thread-local message for the last failure.  Nothing here ever calls exit().
+ *
+ * Streams: `stream` is a hipStream_t passed as void*.  Work is enqueued on it and the call returns without
+ * synchronising, unless the handle was created with COALA_FLAG_SYNC (the reference's behaviour: every native call
+ * ends in cudaDeviceSynchronize, COALA_GNN_Modules/ssd_gnn_cache.cuh:266) in which case the call returns after the
+ * stream has drained.
+ */
+#ifndef COALA_HIP_H
+#define COALA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COALA_OK 0
+#define COALA_EINVAL (-1)   /* bad argument                                    */
+#define COALA_EHIP (-2)     /* a HIP runtime call failed                       */
+#define COALA_ENOMEM (-3)   /* allocation failed                               */
+#define COALA_EIO (-4)      /* file / shm failure                              */
+#define COALA_EFORMAT (-5)  /* malformed .npy                                  */
+#define COALA_ERANGE (-6)   /* an index was outside [0, num_rows)              */
+
+#define COALA_WAYS 32u /* COALA_GNN_Modules/ssd_gnn_cache.cuh:61,204 */
+
+#define COALA_FLAG_SYNC 1u        /* synchronise the stream before returning (reference semantics)            */
+#define COALA_FLAG_DISTRIBUTED 2u /* set = (id / n_gpus) % sets   (nvshmem_cache.h:191-196,347) instead of id % sets */
+#define COALA_FLAG_PROFILE 4u     /* record hipEvents around the probe+gather kernel (see coala_cache_profile) */
+
+const char* coala_last_error(void);
+/* ABI version of this header; bumped on any signature change. */
+int coala_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Cache geometry: replaces SSD_GNN_SSD_Controllers (COALA_GNN_Modules/ssd_gnn_cache.cuh:10-55).
+ * cache_dim = 128/256/512/1024 for dim <= 128/256/512/1024; COALA_EINVAL for dim > 1024 (reference throws).
+ * ------------------------------------------------------------------------------------------------------------ */
+int coala_cache_dim(int dim);
+/* num_sets = (cache_mb * 2^20 / (cache_dim*4)) / 32   (ssd_gnn_cache.cuh:96-97,239-240) */
+uint64_t coala_cache_num_sets(uint64_t cache_mb, int cache_dim);
+
+typedef struct coala_cache coala_cache_t; /* opaque */
+
+typedef struct coala_cache_config {
+    int32_t device;            /* HIP device ordinal (SSD_GNN_SSD_Controllers.cudaDevice)                              */
+    int32_t dim;               /* floats per row of the cold table and of every output row                            */
+    uint64_t cache_mb;         /* cache capacity in MiB (Isolated_Cache ctor `cache_size`, ssd_gnn_cache.cuh:227)      */
+    int32_t n_gpus;            /* GPUs sharing the owner-partitioned cache (1 = isolated)                             */
+    int32_t rank;              /* this GPU's rank in [0, n_gpus)                                                      */
+    int32_t global_rank;       /* only used in print_stats lines (isolated_cache.h:136-138)                           */
+    uint32_t flags;            /* COALA_FLAG_*                                                                        */
+    const float* cold_table;   /* device-visible pointer to fp32 [num_rows, dim]: pinned host (zero-copy) or HBM.      */
+                               /* Replaces `sim_buf` (ssd_gnn_cache.cuh:227; isolated_cache.h:323-331).  Row stride is */
+                               /* `dim` floats (the reference strides by cache_dim: SURVEY.md section 3.3, defect 2).  */
+    uint64_t num_rows;         /* rows of cold_table; ids outside [0,num_rows) are rejected (COALA_ERANGE)            */
+    const int64_t* node_color; /* HOST pointer to int64[num_rows] colours (Node_distributor_pybind::color_buffer_ptr,  */
+                               /* node_distributor_pybind.cuh:226-229) or NULL: copied to the device at creation      */
+    int32_t num_colors;        /* colours are 0..num_colors inclusive (0 = uncoloured); num_colors+1 counters are kept */
+    int32_t reserved;
+    uint64_t max_batch;        /* rows per call to pre-size scratch for (0 = grow on demand)                          */
+} coala_cache_config_t;
+
+/* Replaces Isolated_Cache / SSD_GNN_NVSHMEM_Cache ctors (ssd_gnn_cache.cuh:84-109,227-252) and
+ * Isolated_cache_handle / NVSHMEM_cache_handle ctors (isolated_cache.h:520-636, nvshmem_cache.h:525-640). */
+int coala_cache_create(const coala_cache_config_t* cfg, coala_cache_t** out);
+/* Replaces the destructors (isolated_cache.h:638-653, ssd_gnn_cache.cuh:366-369). */
+int coala_cache_destroy(coala_cache_t* h);
+
+typedef struct coala_cache_geometry {
+    uint64_t num_sets;
+    uint32_t num_ways;
+    uint32_t cache_dim;   /* floats per line */
+    uint64_t line_bytes;  /* cache_dim * 4   */
+    uint64_t table_bytes; /* HBM bytes held by lines + tags + metadata */
+} coala_cache_geometry_t;
+int coala_cache_geometry(const coala_cache_t* h, coala_cache_geometry_t* out);
+
+/* out[i, 0:dim] = cache(idx[i]) for i in [0, n).  Replaces Isolated_Cache::read_feature (ssd_gnn_cache.cuh:255-268),
+ * Isolated_read_feature_kernel (cache_kernel.cu:59-77) and Isolated_cache_d_t::get_data (isolated_cache.h:335-475).
+ * With COALA_FLAG_DISTRIBUTED the set index is the distributed one (see coala_cache_serve).
+ * `out` fp32 [n, dim] and `idx` int64 [n] are device pointers.  Batch-synchronous, deterministic replacement:
+ * every probe sees the pre-call table; misses then take ways (set_cnt + k) % 32 in order of position. */
+int coala_cache_read_feature(coala_cache_t* h, float* out, const int64_t* idx, int64_t n, void* stream);
+
+/* Owner-side serve of the partitioned cache: same as coala_cache_read_feature but always with the distributed set index
+ * set = (id / n_gpus) % sets, whatever the handle's flags.  Replaces Isolated_Cache::nccl_get_feature
+ * (ssd_gnn_cache.cuh:297-325: get_data(id, out, local_size, true)) and SSD_GNN_NVSHMEM_Cache::read_feature
+ * (ssd_gnn_cache.cuh:132-174) minus the transport.  ids = concatenation, in source-rank order, of the ids routed to
+ * this owner; out = packed fp32 [n, dim] in the same order. */
+int coala_cache_serve(coala_cache_t* h, float* out, const int64_t* ids, int64_t n, void* stream);
+
+/* Bucket idx by owner = id % n_parts, stable inside each bucket.  Replaces Isolated_Cache::split_node_list
+ * (ssd_gnn_cache.cuh:283-295) / nccl_split_node_list_kernel (cache_kernel.cu:79-91) and the routing half of
+ * NVSHMEM_send_requests_kernel (cache_kernel.cu:4-17).
+ *   node_out, map_out : int64 device buffers.  bucket_stride > 0: bucket g starts at g*bucket_stride (the reference's
+ *                       [G][max_sample] layout).  bucket_stride == 0: buckets are packed back to back (all-to-all-v
+ *                       send layout) and offsets_out[g] (int64[n_parts+1], device) receives the bucket starts.
+ *   counts_out        : int64[n_parts] device. */
+int coala_cache_route(coala_cache_t* h, const int64_t* idx, int64_t n, int n_parts, int64_t bucket_stride,
+                      int64_t* node_out, int64_t* map_out, int64_t* counts_out, int64_t* offsets_out, void* stream);
+
+/* out[map[r], 0:dim] = src[r, 0:dim] for r in [0, n).  Replaces Isolated_Cache::map_feat_data
+ * (ssd_gnn_cache.cuh:327-356) / nccl_gather_feature_kernel + block_memcpy (cache_kernel.cu:113-137). */
+int coala_cache_scatter(coala_cache_t* h, float* out, const float* src, const int64_t* map, int64_t n, void* stream);
+
+/* Copy the colour occupancy counters to HOST memory dst[0 .. n_entries).  Replaces get_cache_data
+ * (ssd_gnn_cache.cuh:176-186,270-280).  The reference copies num_colors entries; pass num_colors+1 to also get the
+ * last colour.  Synchronises `stream`. */
+int coala_cache_color_counts(coala_cache_t* h, int32_t* dst, int32_t n_entries, void* stream);
+
+/* hit / miss counters since the last reset.  Replaces print_stats_kernel / print_stats (cache_kernel.cu:139-143,
+ * isolated_cache.h:132-141), which print and reset.  Synchronises `stream`.  range_errors counts rejected ids. */
+int coala_cache_stats(coala_cache_t* h, uint64_t* hit, uint64_t* miss, uint64_t* range_errors, int reset, void* stream);
+
+/* Debug / test access to the table (device -> host copies; synchronising).  Any pointer may be NULL.
+ * keys: u64[sets*32]; set_cnt: u32[sets]; color_meta: u32[sets*32]. */
+int coala_cache_dump(coala_cache_t* h, uint64_t* keys, uint32_t* set_cnt, uint32_t* color_meta, void* stream);
+
+/* With COALA_FLAG_PROFILE: accumulated hipEvent time (ms) and launch count of the probe+gather kernel and of the
+ * cold-fill kernel since the last reset; rows_* are the rows each processed.  Synchronises the recorded events. */
+typedef struct coala_cache_profile {
+    double gather_ms;
+    uint64_t gather_launches;
+    uint64_t gather_rows;   /* rows probed */
+    uint64_t gather_hits;   /* rows copied from HBM lines */
+    double fill_ms;
+    uint64_t fill_launches;
+    uint64_t fill_rows;
+    double rank_ms;
+} coala_cache_profile_t;
+int coala_cache_profile(coala_cache_t* h, coala_cache_profile_t* out, int reset);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Shared pinned-host ("UVA") region.  Replaces SharedUVAManager (COALA_GNN_Modules/shared_UVA.cuh:26-115):
+ * creator shm_open+ftruncate, everybody mmap + hipHostRegister + hipHostGetDevicePointer.  The MPI barrier between
+ * create and open (shared_UVA.cuh:76,79) is the caller's job (torch.distributed barrier): is_creator selects the role.
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct coala_shm coala_shm_t;
+int coala_shm_open(const char* name, uint64_t bytes, int is_creator, int device, coala_shm_t** out);
+void* coala_shm_host_ptr(const coala_shm_t* s);   /* SharedUVAManager::get_host_ptr   */
+void* coala_shm_device_ptr(const coala_shm_t* s); /* SharedUVAManager::get_device_ptr */
+int coala_shm_close(coala_shm_t* s, int unlink);  /* SharedUVAManager::cleanup        */
+
+/* Plain pinned host allocation visible to the device (private cold tier; hipHostMalloc mapped). */
+int coala_pinned_alloc(uint64_t bytes, int device, void** host_ptr, void** device_ptr);
+int coala_pinned_free(void* host_ptr);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * .npy reader and node distributor.  Replace parse_numpy_file / load_file_to_memory
+ * (COALA_GNN_Modules/node_distributor_pybind.cuh:11-109) and Node_distributor_pybind (:112-238).
+ * ------------------------------------------------------------------------------------------------------------ */
+/* Parse a .npy v1/v2 header in memory.  want_dim is 1 or 2 (the reference's regex choice); when the stored shape has a
+ * different rank, *ndim_out is 0 and shape is untouched (the reference leaves its vector empty).  descr receives e.g. "<i8". */
+int coala_npy_parse(const char* buf, size_t len, int want_dim, int64_t* shape, int* ndim_out, size_t* data_off,
+                    char* descr, size_t descr_cap);
+
+typedef struct coala_distributor coala_distributor_t;
+/* Node_distributor_pybind(u64 items, int n_nodes)  (node_distributor_pybind.cuh:133-136) */
+int coala_distributor_create_plain(const int64_t* items, int num_nodes, coala_distributor_t** out);
+/* Node_distributor_pybind(u64 items, int node_id, int batch, int local_size, int n_nodes, color, topk, score) (:138-148) */
+int coala_distributor_create(const int64_t* items, int node_id, int batch_size, int local_size, int num_nodes,
+                             const char* color_file, const char* topk_file, const char* score_file,
+                             coala_distributor_t** out);
+int coala_distributor_destroy(coala_distributor_t* d);
+int coala_distributor_num_colors(const coala_distributor_t* d);          /* get_num_colors (:224-226) */
+const int64_t* coala_distributor_color_ptr(const coala_distributor_t* d); /* get_color_buffer_ptr (:228-231) */
+int64_t coala_distributor_num_color_entries(const coala_distributor_t* d);
+/* distribute_node_with_affinity(u64 offset, u64 out, list[u64] meta)  (:150-222).  meta[j] -> int32 counters of domain j,
+ * indexed by colour (num_colors+1 entries).  out -> int64[batch_size*local_size].  Re-entrant per handle. */
+int coala_distributor_assign(const coala_distributor_t* d, uint64_t offset, int64_t* out, const int32_t* const* meta,
+                             int n_meta);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COALA_HIP_H */

@@ -1,0 +1,269 @@
+#!/usr/bin/env python3
+"""bench.py -- feature-gather throughput of the MI355X feature-cache path on the IGB-medium GraphSAGE workload.
+
+  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one minibatch of the hot path: the sampled input-node ids (already resident in HBM) go through
+COALA_GNN_Manager.fetch_feature -> libcoala_hip.so (probe + hit gather, deterministic miss ranking, cold fill from the
+pinned-host table; for N>1 the owner-partitioned cache with RCCL all-to-all-v) and come back as the fp32 [n, 1024]
+feature tensor in HBM.  Workload at N=1 = BASELINE.json configs[1]: IGB-medium shape (10,000,000 x 1024 fp32 cold table
+in pinned host memory), GraphSAGE fan-out 5,5, batch 1024, isolated 4 GiB cache.  N>1 keeps the same per-GPU work
+(weak scaling) with the cache sharded by id % N.  Synthetic data: no datasets on the box.
+
+Prints ONE JSON line (rank 0) with metric/value/... plus "roofline" (probe+gather kernel, hipEvents on its stream over
+the timed region) and "cpu_baseline" (the C oracle, one host core, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "coala-gnn_amd")
+for _p in (ROOT, PKG):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--rows", type=int, default=10_000_000, help="nodes of the synthetic graph / rows of the table")
+    ap.add_argument("--dim", type=int, default=1024)
+    ap.add_argument("--fanout", type=str, default="5,5")
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--cache-mb", type=int, default=4096)
+    ap.add_argument("--avg-degree", type=float, default=12.0)
+    ap.add_argument("--prewarm", type=int, default=400, help="untimed minibatches that bring the cache to steady state")
+    ap.add_argument("--backend", type=str, default=None, help="isolated | nccl | nvshmem (default: isolated at N=1, nccl otherwise)")
+    ap.add_argument("--mode", type=str, default="minibatch", choices=["minibatch", "allhit", "allmiss"],
+                    help="minibatch: sampler-produced ids (the metric). allhit/allmiss: kernel micro-benchmarks on unique uniform ids")
+    ap.add_argument("--cpu-baseline-batches", type=int, default=120)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=0)
+    return ap.parse_args()
+
+
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
+def main():
+    args = parse_args()
+    fanout = [int(f) for f in args.fanout.split(",")]
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    device = f"cuda:{local_rank}"
+
+    import __graft_entry__ as entry
+    if rank == 0:
+        entry._load_build_module().build_lib()
+    from COALA_GNN import MPI_Comm_Manager, Shared_UVA_Tensor_Manager
+    from COALA_GNN.COALA_GNN_Manager import COALA_GNN_Manager
+    from COALA_GNN.synthetic import PinnedFeatureTable, fill_table, powerlaw_csc
+    from COALA_GNN.sampler import NeighborSampler
+
+    backend = args.backend or ("isolated" if world == 1 else "nccl")
+    comm = MPI_Comm_Manager(0)                    # one machine: every rank in domain 0
+    comm.initialize_nested_process_group(backend)
+
+    # ---------------------------------------------------------------- cold tier: fp32 [rows, dim] in pinned host memory
+    t0 = time.time()
+    nbytes = args.rows * args.dim * 4
+    if world == 1:
+        table = PinnedFeatureTable(args.rows, args.dim, local_rank)
+        fill_table(table.cpu_tensor, args.seed, device=device)
+        sim_ptr_owner = table
+        host_array = table.array
+    else:
+        shm = Shared_UVA_Tensor_Manager(comm, f"/coala_bench_feat_{os.environ.get('MASTER_PORT', '0')}", nbytes)
+        host_array = shm.get_host_array(np.float32, (args.rows, args.dim))
+        lo = args.rows * comm.local_rank // comm.local_size
+        hi = args.rows * (comm.local_rank + 1) // comm.local_size
+        fill_table(torch.from_numpy(host_array[lo:hi]), args.seed, device=device, row0=lo)
+        comm.local_comm.Barrier()
+
+        class _Alias:  # what COALA_GNN_Manager needs from sim_buf: data_ptr() and shape
+            shape = (args.rows, args.dim)
+
+            @staticmethod
+            def data_ptr():
+                return shm.device_ptr
+        sim_ptr_owner = _Alias()
+    log(f"cold table {nbytes / 1e9:.2f} GB pinned + filled in {time.time() - t0:.1f}s")
+
+    # ---------------------------------------------------------------- graph + train ids
+    t0 = time.time()
+    indptr, indices = powerlaw_csc(args.rows, args.avg_degree, seed=args.seed, device=device)
+    n_train = int(0.6 * args.rows)                # examples/ssd_gnn_dataloader.py:550-559
+    g = torch.Generator().manual_seed(0)
+    train_ids = torch.randperm(n_train, generator=g)
+    steps_per_epoch = n_train // (args.batch * world) - 1  # COALA_GNN_DataLoader.py:141
+    sampler = NeighborSampler(fanout, seed=args.seed)
+    graph = sampler.make_graph(indptr, indices)
+    log(f"graph {args.rows} nodes / {indices.numel()} edges built in {time.time() - t0:.1f}s")
+
+    manager = COALA_GNN_Manager(node_distributor=None, num_ssds=1, page_size=args.dim * 4, num_elems=1024, ssd_read_offset=0,
+                                cache_size=args.cache_mb, batch_size=args.batch, fan_out=fanout, dim=args.dim,
+                                MPI_comm_manager=comm, device=device, cache_backend=backend, sim_buf=sim_ptr_owner,
+                                num_rows=args.rows, profile=True)
+    cache = manager.COALA_GNN_Cache
+    max_rows = manager.max_sample_size
+
+    total_steps = args.prewarm + args.warmup + args.steps
+
+    def seeds_for(step):  # rank r takes the r-th batch of the global batch (COALA_GNN_DataLoader.py:72-73)
+        lo = ((step % max(steps_per_epoch, 1)) * world + rank) * args.batch
+        return train_ids[lo: lo + args.batch].to(device)
+
+    def ids_for(step):
+        if args.mode == "minibatch":
+            return sampler.sample(graph, seeds_for(step))[0]
+        gen = torch.Generator(device=device).manual_seed(1000 * step + rank if args.mode == "allmiss" else rank)
+        return torch.randperm(args.rows, generator=gen, device=device)[:max_rows]
+
+    # ---------------------------------------------------------------- untimed: bring the cache to its steady state
+    t0 = time.time()
+    for s in range(args.prewarm):
+        manager.fetch_feature((ids_for(s),))
+    torch.cuda.synchronize()
+    log(f"prewarm {args.prewarm} minibatches in {time.time() - t0:.1f}s")
+    batches = [ids_for(args.prewarm + s) for s in range(args.warmup + args.steps)]  # resident in HBM before timing
+    torch.cuda.synchronize()
+
+    for s in range(args.warmup):
+        manager.fetch_feature((batches[s],))
+    torch.cuda.synchronize()
+    cache.stats(reset=True)
+    cache.profile(reset=True)
+
+    # ---------------------------------------------------------------- timed region
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    rows_done = 0
+    for s in range(args.warmup, args.warmup + args.steps):
+        out = manager.fetch_feature((batches[s],))[-1]
+        rows_done += out.shape[0]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_start
+
+    hit, miss, bad = cache.stats()
+    prof = cache.profile()
+    stat = torch.tensor([elapsed, float(rows_done), float(hit), float(miss)], dtype=torch.float64, device=device)
+    if world > 1:
+        tmax = stat.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(stat, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0])
+        rows_all, hit_all, miss_all = float(stat[1]), float(stat[2]), float(stat[3])
+    else:
+        rows_all, hit_all, miss_all = float(rows_done), float(hit), float(miss)
+
+    payload_bytes = rows_all * args.dim * 4
+    value = payload_bytes / elapsed / 1e9
+    ms_per_step = elapsed / args.steps * 1e3
+
+    # ---------------------------------------------------------------- roofline of the probe+gather kernel (rank 0)
+    # algorithmic bytes per launch (DESIGN.md "Kernels"): every probed row reads its int64 id and one 32x8 B tag set;
+    # every hit additionally reads a dim*4 line and writes a dim*4 output row  (B_row = 2*dim*4+8+256)
+    launches = max(prof.gather_launches, 1)
+    alg_bytes = prof.gather_rows * (8 + 256) + prof.gather_hits * (2 * args.dim * 4)
+    k_ms = prof.gather_ms / launches
+    achieved = (alg_bytes / launches) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    roofline = {
+        "bound": "hbm", "kernel": "probe_gather_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": _pmc_traffic(),
+        "avg_launch_us": round(k_ms * 1e3, 2), "launches": int(prof.gather_launches),
+        "rows_per_launch": round(prof.gather_rows / launches, 1), "hits_per_launch": round(prof.gather_hits / launches, 1),
+        "alg_bytes_per_launch": int(alg_bytes / launches),
+        "cold_fill_avg_us": round(prof.fill_ms / max(prof.fill_launches, 1) * 1e3, 2),
+        "rank_avg_us": round(prof.rank_ms / max(prof.fill_launches, 1) * 1e3, 2),
+    }
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_baseline = run_cpu_baseline(args, host_array, batches[args.warmup:], fanout)
+
+    if rank == 0:
+        line = {
+            "metric": "feature-gather GB/s (payload = rows x dim x 4 B delivered per second), IGB-medium GraphSAGE minibatch fetch",
+            "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"IGB-medium-shaped {args.rows}x{args.dim} fp32 cold table in pinned host memory, "
+                                   f"GraphSAGE fan-out {args.fanout} bs={args.batch}, {backend} cache {args.cache_mb} MiB/GPU, "
+                                   f"mode={args.mode}",
+                       "rows_per_step_per_gpu": round(rows_all / world / args.steps, 1),
+                       "hit_ratio": round(hit_all / max(hit_all + miss_all, 1.0), 4),
+                       "cache_backend": backend, "prewarm_steps": args.prewarm,
+                       "steps_per_epoch": steps_per_epoch,
+                       "epoch_time_s_fetch_only_extrapolated": round(ms_per_step * steps_per_epoch / 1e3, 2)},
+            "roofline": roofline,
+            "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+    del manager
+    if world > 1:
+        comm.destroy_process_group()
+
+
+def _pmc_traffic():
+    """HBM bytes per launch of the probe+gather kernel from the committed rocprofv3 PMC pass (profiles/), or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_probe_gather.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def run_cpu_baseline(args, host_array, batches, fanout):
+    """The CPU oracle (oracle/coala_oracle.c: a port, the reference itself cannot be built here) on one host core,
+    over a bounded sample of the same minibatches."""
+    from oracle import oracle as O
+    nb = min(args.cpu_baseline_batches, len(batches))
+    if nb == 0:
+        return None
+    idx_host = [b.cpu().numpy() for b in batches[:nb]]
+    orc = O.OracleCache(args.cache_mb, args.dim, host_array)
+    t0 = time.perf_counter()
+    rows = 0
+    for ids in idx_host:
+        orc.read_feature(ids, O.SCHED_HITS_FIRST)
+        rows += len(ids)
+        if time.perf_counter() - t0 > 30.0:
+            break
+    dt = time.perf_counter() - t0
+    orc.close()
+    return {"value": round(rows * args.dim * 4 / dt / 1e9, 3), "unit": "GB/s", "cores": 1, "kind": "port",
+            "sample": f"{rows} rows of the first minibatches of the timed region through the C oracle (cold oracle cache), {dt:.1f}s",
+            "host_cpus": os.cpu_count()}
+
+
+if __name__ == "__main__":
+    main()

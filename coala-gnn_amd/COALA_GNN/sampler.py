@@ -1,0 +1,124 @@
+"""Native neighbour sampler for the COALA_GNN_DataLoader: `NeighborSampler(fanouts).sample(graph, seeds)`.
+
+Stands where the reference passes dgl.dataloading.MultiLayerNeighborSampler (examples/sbatch_ssd_gnn_train.py:70-72; used
+at COALA-GNN-Setup/COALA_GNN/COALA_GNN_DataLoader.py:162).  DGL is not installed on the MI355X image; any object with the
+same .sample(graph, seeds) -> (input_nodes, output_nodes, blocks) still works with the loader.  The kernels are in
+coala-gnn_amd/csrc/coala_sampler.hip (C ABI: coala_sampler_*).  The CSC arrays live in HBM (the reference keeps them in
+shared pinned host memory and samples over PCIe: examples/ssd_gnn_dataloader.py:496-523)."""
+import ctypes as C
+
+import torch
+
+from COALA_GNN_Pybind import _capi, current_stream
+
+__all__ = ["NeighborSampler", "CSCGraph", "Block"]
+
+_lib = _capi.load()
+
+
+class CSCGraph(object):
+    """int64 CSC (indptr[N+1], indices[E]) resident on one GPU + per-node data (labels...)."""
+
+    def __init__(self, indptr, indices, ndata=None):
+        assert indptr.dtype == torch.int64 and indices.dtype == torch.int64
+        assert indptr.is_cuda and indices.is_cuda, "the CSC arrays must be device tensors (HBM or a pinned-host alias)"
+        self.indptr, self.indices = indptr.contiguous(), indices.contiguous()
+        self.num_nodes = self.indptr.numel() - 1
+        self.num_edges = self.indices.numel()
+        self.device = self.indptr.device
+        self.ndata = dict(ndata or {})
+        self._h = C.c_void_p()
+        dev = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        _capi.check(_lib.coala_sampler_create(dev, self.indptr.data_ptr(), self.indices.data_ptr(), self.num_nodes,
+                                              self.num_edges, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.coala_sampler_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Block(object):
+    """One message-flow block in fixed-stride form: dst node d aggregates src rows nbr[d, j] >= 0.
+    The first num_dst source nodes ARE the destination nodes (DGL's to_block convention)."""
+
+    def __init__(self, src_nodes, nbr, num_dst, graph=None):
+        self.src_nodes = src_nodes          # int64 [num_src] global ids
+        self.nbr = nbr                      # int32 [num_dst, fanout], -1 padded
+        self.num_src = int(src_nodes.numel())
+        self.num_dst = int(num_dst)
+        self.srcdata = {"_ID": src_nodes}
+        self.dstdata = {"_ID": src_nodes[: self.num_dst]}
+        if graph is not None:
+            for k, v in graph.ndata.items():  # blocks[-1].dstdata['labels'] (examples/sbatch_ssd_gnn_train.py:138)
+                self.dstdata[k] = v[self.dstdata["_ID"]] if v.device == src_nodes.device else v[self.dstdata["_ID"].cpu()]
+
+    def number_of_src_nodes(self):
+        return self.num_src
+
+    def number_of_dst_nodes(self):
+        return self.num_dst
+
+    def int(self):   # examples/sbatch_ssd_gnn_train.py:139  block.int().to(device)
+        return self
+
+    def to(self, device):
+        return self
+
+    def mean_aggregate(self, h_src):
+        """Mean of the sampled neighbours' rows for every dst node: fp32 [num_dst, dim] (GraphSAGE 'mean')."""
+        valid = self.nbr >= 0
+        idx = self.nbr.clamp_min(0).to(torch.int64)
+        g = h_src[idx] * valid.unsqueeze(-1).to(h_src.dtype)
+        return g.sum(1) / valid.sum(1).clamp_min(1).unsqueeze(-1).to(h_src.dtype)
+
+
+class NeighborSampler(object):
+    def __init__(self, fanouts, seed=0):
+        self.fanouts = [int(f) for f in fanouts]
+        if not 1 <= len(self.fanouts) <= 8:
+            raise ValueError("1..8 layers")
+        self.seed = int(seed)
+        self.step = 0
+
+    @staticmethod
+    def make_graph(indptr, indices, ndata=None):
+        return CSCGraph(indptr, indices, ndata)
+
+    def sample(self, g, seed_nodes, step=None):
+        """-> (input_nodes, output_nodes, blocks), blocks[0] is the input layer (DGL order)."""
+        if isinstance(g, tuple):
+            g = CSCGraph(*g)
+        seeds = seed_nodes.to(g.device, dtype=torch.int64).contiguous()
+        n = seeds.numel()
+        rev = list(reversed(self.fanouts))          # DGL samples the output layer first
+        L = len(rev)
+        caps = [n]
+        for f in rev:
+            caps.append(caps[-1] * (f + 1))
+        src = [torch.empty(max(caps[l + 1], 1), dtype=torch.int64, device=g.device) for l in range(L)]
+        nbr = [torch.empty(max(caps[l] * rev[l], 1), dtype=torch.int32, device=g.device) for l in range(L)]
+        src_p = (C.c_void_p * L)(*[t.data_ptr() for t in src])
+        nbr_p = (C.c_void_p * L)(*[t.data_ptr() for t in nbr])
+        fan = (C.c_int32 * L)(*rev)
+        n_src = (C.c_int64 * L)()
+        st = self.step if step is None else int(step)
+        _capi.check(_lib.coala_sampler_sample(g._h, seeds.data_ptr(), n, fan, L, self.seed, st, src_p, nbr_p, n_src,
+                                              current_stream()))
+        if step is None:
+            self.step += 1
+        blocks = []
+        n_dst = n
+        for l in range(L):
+            ns = int(n_src[l])
+            blocks.insert(0, Block(src[l][:ns], nbr[l][: n_dst * rev[l]].view(n_dst, rev[l]), n_dst,
+                                   graph=g if l == 0 else None))
+            n_dst = ns
+        input_nodes = blocks[0].src_nodes
+        return input_nodes, seeds, blocks

@@ -50,6 +50,10 @@ SYMBOLS = {
     "coala_cache_stats": (_I, [_VP, C.POINTER(_U64), C.POINTER(_U64), C.POINTER(_U64), _I, _VP]),
     "coala_cache_dump": (_I, [_VP, _VP, _VP, _VP, _VP]),
     "coala_cache_profile": (_I, [_VP, C.POINTER(CacheProfile), _I]),
+    "coala_sampler_create": (_I, [_I, _VP, _VP, _I64, _I64, C.POINTER(_VP)]),
+    "coala_sampler_destroy": (_I, [_VP]),
+    "coala_sampler_sample": (_I, [_VP, _VP, _I64, C.POINTER(C.c_int32), _I, _U64, _U64, C.POINTER(_VP), C.POINTER(_VP),
+                             C.POINTER(_I64), _VP]),
     "coala_shm_open": (_I, [C.c_char_p, _U64, _I, _I, C.POINTER(_VP)]),
     "coala_shm_host_ptr": (_VP, [_VP]),
     "coala_shm_device_ptr": (_VP, [_VP]),

@@ -139,6 +139,31 @@ typedef struct coala_cache_profile {
 int coala_cache_profile(coala_cache_t* h, coala_cache_profile_t* out, int reset);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Neighbour sampler + block compaction over a CSC graph resident in device-visible memory (HBM, or pinned host).
+ * Replaces the DGL call on the hot path: graph_sampler.sample(g, seeds) with
+ * dgl.dataloading.MultiLayerNeighborSampler(fanouts) (COALA-GNN-Setup/COALA_GNN/COALA_GNN_DataLoader.py:162,
+ * examples/sbatch_ssd_gnn_train.py:70-72; graph: examples/ssd_gnn_dataloader.py:523).  DGL's arithmetic is not under
+ * /root/reference; the contract (coala_sampler.hip header) is pinned by properties and by the CPU twin in oracle/.
+ * ------------------------------------------------------------------------------------------------------------ */
+#define COALA_SAMPLER_MAX_LAYERS 8
+typedef struct coala_sampler coala_sampler_t;
+/* indptr int64[num_nodes+1], indices int64[num_edges]: device-visible, borrowed for the sampler's lifetime. */
+int coala_sampler_create(int device, const int64_t* indptr, const int64_t* indices, int64_t num_nodes, int64_t num_edges,
+                         coala_sampler_t** out);
+int coala_sampler_destroy(coala_sampler_t* s);
+/* Sample n_layers layers starting from `seeds` (device int64[n_seeds]).  fanouts[l] is the fan-out of the l-th SAMPLED
+ * layer (DGL walks reversed(fanouts): pass them already reversed).  Layer l's destination nodes are layer l-1's source
+ * nodes.  Outputs, all device buffers owned by the caller, for cap_0 = n_seeds, cap_{l+1} = cap_l*(fanouts[l]+1):
+ *   src_nodes_out[l] : int64[cap_{l+1}]        source (input) nodes of block l: its dst nodes first, then new ones
+ *   nbr_local_out[l] : int32[cap_l*fanouts[l]] row d holds the local indices of dst d's sampled neighbours, -1 padded
+ *   n_src_host[l]    : HOST int64, number of source nodes of block l (the call synchronises `stream` to deliver it;
+ *                      pass NULL to stay asynchronous and read the counts yourself later)
+ * Randomness: counter-based, keyed by (seed, step, layer, node id): same arguments, same sample. */
+int coala_sampler_sample(coala_sampler_t* s, const int64_t* seeds, int64_t n_seeds, const int32_t* fanouts, int n_layers,
+                         uint64_t seed, uint64_t step, int64_t* const* src_nodes_out, int32_t* const* nbr_local_out,
+                         int64_t* n_src_host, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Shared pinned-host ("UVA") region.  Replaces SharedUVAManager (COALA_GNN_Modules/shared_UVA.cuh:26-115):
  * creator shm_open+ftruncate, everybody mmap + hipHostRegister + hipHostGetDevicePointer.  The MPI barrier between
  * create and open (shared_UVA.cuh:76,79) is the caller's job (torch.distributed barrier): is_creator selects the role.

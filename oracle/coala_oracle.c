@@ -317,3 +317,65 @@ void orc_fill_features(float* dst, uint64_t row0, uint64_t nrows, uint32_t dim, 
     for (uint64_t r = 0; r < nrows; ++r)
         for (uint32_t c = 0; c < dim; ++c) dst[r * dim + c] = orc_feat_value(row0 + r, c, seed);
 }
+
+/* ---------------------------------------------------------------- neighbour sampler twin (contract of coala_sampler.hip) */
+
+static uint64_t orc_splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+static uint64_t orc_sample_key(uint64_t seed, uint64_t step, int layer, uint64_t v) {
+    uint64_t h = orc_splitmix64(seed ^ (0x9E3779B97F4A7C15ull * (uint64_t)(layer + 1)));
+    h = orc_splitmix64(h ^ (step * 0xD1B54A32D192ED03ull));
+    return orc_splitmix64(h ^ v);
+}
+
+void orc_sample_layer(const int64_t* indptr, const int64_t* indices, int64_t num_nodes, const int64_t* dst, int64_t n_dst,
+                      int fanout, uint64_t seed, uint64_t step, int layer, int64_t* nbr) {
+    for (int64_t d = 0; d < n_dst; ++d) {
+        int64_t v = dst[d];
+        int64_t* row = nbr + d * fanout;
+        if (v < 0 || v >= num_nodes) { for (int j = 0; j < fanout; ++j) row[j] = -1; continue; }
+        int64_t start = indptr[v], deg = indptr[v + 1] - start;
+        if (deg <= fanout) { for (int j = 0; j < fanout; ++j) row[j] = j < deg ? indices[start + j] : -1; continue; }
+        uint64_t key = orc_sample_key(seed, step, layer, (uint64_t)v);
+        int64_t chosen[32];
+        int c = 0;
+        for (int64_t j = deg - fanout; j < deg; ++j) { /* Floyd's subset sampling */
+            uint64_t r = orc_splitmix64(key + (uint64_t)c);
+            int64_t t = (int64_t)(((unsigned __int128)r * (unsigned __int128)(uint64_t)(j + 1)) >> 64);
+            int dup = 0;
+            for (int q = 0; q < c; ++q) dup |= (chosen[q] == t);
+            if (dup) t = j;
+            chosen[c++] = t;
+        }
+        for (int j = 0; j < fanout; ++j) row[j] = indices[start + chosen[j]];
+    }
+}
+
+typedef struct { int64_t key; int32_t val; } orc_slot;
+
+int64_t orc_compact_block(const int64_t* dst, int64_t n_dst, const int64_t* nbr, int fanout, int64_t* src_out, int32_t* local) {
+    int64_t n_items = n_dst * (fanout + 1);
+    uint64_t cap = 16;
+    while (cap < 2 * (uint64_t)(n_items > 0 ? n_items : 1)) cap *= 2;
+    orc_slot* tab = (orc_slot*)malloc(cap * sizeof(orc_slot));
+    for (uint64_t i = 0; i < cap; ++i) tab[i].key = -1;
+    int64_t n_src = 0;
+    for (int64_t p = 0; p < n_items; ++p) { /* sequential scan == first-appearance order */
+        int64_t k = p < n_dst ? dst[p] : nbr[p - n_dst];
+        int32_t loc = -1;
+        if (k >= 0) {
+            uint64_t s = orc_splitmix64((uint64_t)k) & (cap - 1);
+            while (tab[s].key != -1 && tab[s].key != k) s = (s + 1) & (cap - 1);
+            if (tab[s].key == -1) { tab[s].key = k; tab[s].val = (int32_t)n_src; src_out[n_src++] = k; }
+            loc = tab[s].val;
+        }
+        if (p >= n_dst) local[p - n_dst] = loc;
+    }
+    free(tab);
+    return n_src;
+}

@@ -71,6 +71,10 @@ def lib():
         L.orc_feat_value.restype = C.c_float
         L.orc_feat_value.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
         L.orc_fill_features.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]
+        L.orc_sample_layer.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_uint64,
+                                       C.c_uint64, C.c_int, C.c_void_p]
+        L.orc_compact_block.restype = C.c_int64
+        L.orc_compact_block.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -215,6 +219,25 @@ def distribute_node_with_affinity(items, offset, batch_size, local_size, node_id
     lib().orc_distribute_node_with_affinity(_ptr(items), int(offset), domain * num_nodes, domain, int(node_id),
                                             int(num_nodes), _ptr(color), _ptr(topk), _ptr(score), topk.shape[1], mp,
                                             _ptr(out))
+    return out
+
+
+def sample_blocks(indptr, indices, seeds, fanouts_reversed, seed, step):
+    """Multi-layer twin of coala_sampler_sample: returns [(src_nodes int64[n_src], nbr_local int32[n_dst, f]), ...]."""
+    indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(indices, dtype=np.int64)
+    dst = np.ascontiguousarray(seeds, dtype=np.int64)
+    out = []
+    for layer, f in enumerate(fanouts_reversed):
+        nbr = np.empty(len(dst) * f, dtype=np.int64)
+        lib().orc_sample_layer(_ptr(indptr), _ptr(indices), len(indptr) - 1, _ptr(dst), len(dst), int(f), int(seed), int(step),
+                               layer, _ptr(nbr))
+        src = np.empty(len(dst) * (f + 1), dtype=np.int64)
+        local = np.empty(len(dst) * f, dtype=np.int32)
+        n_src = lib().orc_compact_block(_ptr(dst), len(dst), _ptr(nbr), int(f), _ptr(src), _ptr(local))
+        src = src[:n_src].copy()
+        out.append((src, local.reshape(len(dst), f), nbr.reshape(len(dst), f)))
+        dst = src
     return out
 
 

@@ -1,0 +1,110 @@
+"""Owner-partitioned cache on ONE GPU with G logical ranks in one process (loopback exchange): exercises the real route /
+serve / scatter kernels and the AllToAllExchange host logic's contract against the oracle's collective step
+(orc_dist_fetch: COALA_GNN_Manager.py:143-211, ssd_gnn_cache.cuh:111-174).  The RCCL transport itself is covered by
+test_manager_world1_gpu (1-rank RCCL group) and by the gloo world-2 CPU tests."""
+import numpy as np
+import pytest
+
+from _util import PinnedTable
+
+pytestmark = pytest.mark.gpu
+
+
+def _loopback_step(torch, caches, idx_list, dim):
+    """What G ranks + all-to-all-v do, in one process: route on every rank, concatenate per owner in source-rank order,
+    serve, hand the rows back, un-permute."""
+    G = len(caches)
+    routed = []
+    for r in range(G):
+        idx = idx_list[r]
+        n = idx.numel()
+        node = torch.empty(max(n, 1), dtype=torch.int64, device="cuda")
+        mp = torch.empty(max(n, 1), dtype=torch.int64, device="cuda")
+        cnt = torch.zeros(G, dtype=torch.int64, device="cuda")
+        off = torch.zeros(G + 1, dtype=torch.int64, device="cuda")
+        caches[r].route(idx.data_ptr(), n, G, node.data_ptr(), mp.data_ptr(), cnt.data_ptr(), off.data_ptr(), 0)
+        routed.append((node, mp, cnt.cpu().tolist(), off.cpu().tolist()))
+    outs = [torch.full((idx_list[r].numel(), dim), -3.0, dtype=torch.float32, device="cuda") for r in range(G)]
+    recv_rows = [[None] * G for _ in range(G)]
+    for o in range(G):
+        parts = [routed[s][0][routed[s][3][o]: routed[s][3][o] + routed[s][2][o]] for s in range(G)]
+        ids = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.int64, device="cuda")
+        rows = torch.empty((max(ids.numel(), 1), dim), dtype=torch.float32, device="cuda")
+        caches[o].serve(rows.data_ptr(), ids.data_ptr(), ids.numel())
+        pos = 0
+        for s in range(G):
+            recv_rows[s][o] = rows[pos: pos + routed[s][2][o]]
+            pos += routed[s][2][o]
+    for r in range(G):
+        n = idx_list[r].numel()
+        if n == 0:
+            continue
+        packed = torch.cat([recv_rows[r][o] for o in range(G)])
+        caches[r].scatter(outs[r].data_ptr(), packed.contiguous().data_ptr(), routed[r][1].data_ptr(), n)
+    return outs
+
+
+@pytest.mark.parametrize("G,dim,cache_mb", [(2, 1024, 1), (4, 128, 1), (3, 100, 1), (8, 1024, 2)])
+def test_partitioned_cache_matches_oracle(hiplib, oracle, G, dim, cache_mb):
+    import torch
+    P = hiplib
+    num_rows = 12000
+    feat = oracle.make_features(num_rows, dim, seed=4)
+    table = PinnedTable(P, feat)
+    ctrl = P.SSD_GNN_SSD_Controllers(1, 4096, 1024, 0, 0, dim, True)
+    caches = [P.SSD_GNN_NVSHMEM_Cache(ctrl, None, r, G, cache_mb, table.device_ptr, num_rows=num_rows) for r in range(G)]
+    orcs = [oracle.OracleCache(cache_mb, dim, feat, n_gpus=G, distributed=True) for _ in range(G)]
+    rng = np.random.default_rng(G)
+    for step in range(6):
+        sizes = [int(rng.integers(0, 3000)) if step else 1500 for _ in range(G)]
+        if step == 3:
+            sizes[0] = 0  # a rank with an empty batch
+        idx_np = [rng.choice(num_rows // 2, size=s, replace=False).astype(np.int64) for s in sizes]
+        idx_t = [torch.from_numpy(i).cuda() if len(i) else torch.zeros(0, dtype=torch.int64, device="cuda") for i in idx_np]
+        outs = _loopback_step(torch, caches, idx_t, dim)
+        want = oracle.dist_fetch(orcs, idx_np, oracle.SCHED_HITS_FIRST)
+        for r in range(G):
+            assert outs[r].cpu().numpy().tobytes() == feat[idx_np[r]].tobytes() == want[r].tobytes()
+            assert caches[r].stats()[:2] == (orcs[r].hit_cnt, orcs[r].miss_cnt), f"owner {r} counters differ at step {step}"
+            keys, cnt, _ = caches[r].dump()
+            assert np.array_equal(keys, orcs[r].keys()) and np.array_equal(cnt, orcs[r].set_cnt())
+            # an owner only ever caches ids it owns
+            live = keys[keys != np.uint64(0xFFFFFFFFFFFFFFFF)]
+            assert np.all(live % np.uint64(G) == np.uint64(r))
+    assert sum(o.hit_cnt for o in orcs) > 0
+    for c in caches:
+        c.close()
+    table.close()
+
+
+@pytest.mark.parametrize("backend", ["isolated", "nccl", "nvshmem"])
+def test_manager_world1_gpu(hiplib, oracle, backend):
+    """COALA_GNN_Manager.fetch_feature on one rank for every backend string: G = 1 degenerates to the isolated cache
+    (SURVEY.md section 8e); the nccl/nvshmem flavours still run route -> exchange -> serve -> scatter."""
+    import torch
+    from COALA_GNN import MPI_Comm_Manager
+    from COALA_GNN.COALA_GNN_Manager import COALA_GNN_Manager
+    from COALA_GNN.synthetic import alloc_pinned_table
+    dim, rows = 256, 30000
+    table = alloc_pinned_table(rows, dim, seed=2, device=0)
+    feat = oracle.make_features(rows, dim, seed=2)
+    comm = MPI_Comm_Manager(0)
+    comm.initialize_nested_process_group(backend)
+    mgr = COALA_GNN_Manager(None, 1, dim * 4, 1024, 0, 8, 64, [5, 5], dim, comm, "cuda:0", cache_backend=backend,
+                            sim_buf=table, num_rows=rows)
+    assert mgr.max_sample_size == 64 * 36
+    orc = oracle.OracleCache(8, dim, feat, n_gpus=1, distributed=backend != "isolated")
+    rng = np.random.default_rng(1)
+    for step in range(5):
+        idx = rng.choice(rows // 3, size=2000, replace=False).astype(np.int64)
+        t_idx = torch.from_numpy(idx).cuda()
+        batch = mgr.fetch_feature((t_idx, None, None))
+        assert batch[0] is t_idx and len(batch) == 4
+        got = batch[-1]
+        assert got.shape == (2000, dim) and got.dtype == torch.float32
+        want = orc.read_feature(idx, oracle.SCHED_HITS_FIRST)
+        assert got.cpu().numpy().tobytes() == want.tobytes()
+        assert mgr.COALA_GNN_Cache.stats()[:2] == (orc.hit_cnt, orc.miss_cnt)
+    assert mgr.get_aggregate_time() > 0
+    del mgr
+    table.close()

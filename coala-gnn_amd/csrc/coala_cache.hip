@@ -51,7 +51,7 @@ struct CacheDev {
     int32_t sshift;        // log2(num_sets) if power of two else -1
     uint32_t distributed;
     // per-batch scratch
-    uint32_t* miss_count;  // [2], slot = gen & 1
+    uint32_t* miss_count;  // [4]: [gen&1] misses of this batch, [2 + (gen&1)] rejected ids of this batch
     uint64_t* set_head;    // [sets] : (gen << 32) | (miss index + 1)
     uint32_t* miss_pos;    // [cap] position in the batch
     uint32_t* miss_next;   // [cap] chain link (miss index + 1, 0 = end)
@@ -101,7 +101,7 @@ struct Geo {
 // ---------------------------------------------------------------------------------------------------------- K1
 // Probe R rows, copy the hits, enqueue the misses.
 template <int CD, int VEC>
-__global__ __launch_bounds__(256) void probe_gather_kernel(CacheDev c, const int64_t* __restrict__ idx,
+__global__ __launch_bounds__(1024) void probe_gather_kernel(CacheDev c, const int64_t* __restrict__ idx,
                                                            float* __restrict__ out, int64_t n, uint32_t gen) {
     using G = Geo<CD, VEC>;
     using V = typename VecT<VEC>::type;
@@ -112,8 +112,38 @@ __global__ __launch_bounds__(256) void probe_gather_kernel(CacheDev c, const int
     const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
     const int64_t n_chunks = (n + R - 1) / R;
     const uint32_t nunits = c.dim / VEC; // accesses per output row
-    unsigned long long hits_acc = 0;
-
+    // Misses found by this wave wait in its LDS slice; the block appends them to the global miss list with ONE
+    // same-address atomic when it is done (256 blocks -> 256 atomics per batch).  Measured: an append per chunk, or
+    // even per wave, serialises at ~12 ns each on one address -- 4096 waves = 49 us, as long as the whole hit gather.
+    constexpr int kPendCap = 448;                    // per-wave staging entries (16 waves x 448 x 4 B = 28 KiB LDS)
+    __shared__ uint32_t s_pend[16][kPendCap];
+    __shared__ uint32_t s_cnt[16];
+    __shared__ uint32_t s_base;
+    const int w_in_b = threadIdx.x >> 6;
+    uint32_t* pend = s_pend[w_in_b];
+    uint32_t npend = 0;
+    auto publish = [&](uint32_t first_m, uint32_t count) { // lanes push `count` staged misses as list entries first_m..
+        for (uint32_t e = lane; e < count; e += 64) {
+            const uint32_t pos = pend[e];
+            const uint64_t id = (uint64_t)idx[pos];
+            const uint64_t set = set_of(c, id);
+            const uint32_t m = first_m + e;
+            const unsigned long long tag = ((unsigned long long)gen << 32) | (unsigned long long)(m + 1);
+            const unsigned long long prev = atomicExch(reinterpret_cast<unsigned long long*>(c.set_head + set), tag);
+            c.miss_pos[m] = pos;
+            c.miss_next[m] = ((uint32_t)(prev >> 32) == gen) ? (uint32_t)prev : 0u;
+        }
+    };
+    auto wave_flush = [&]() { // overflow valve only: a wave's slice is full before the block is done
+        uint32_t basem = 0;
+        if (lane == 0) basem = atomicAdd(c.miss_count + (gen & 1), npend);
+        basem = __builtin_amdgcn_readfirstlane(basem);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        publish(basem, npend);
+        __builtin_amdgcn_wave_barrier();
+        npend = 0;
+    };
     for (int64_t chunk = wave; chunk < n_chunks; chunk += n_waves) {
         const int64_t base = chunk * R;
         uint32_t slot[R];       // wave-uniform: set*32 + way for hits
@@ -190,37 +220,42 @@ __global__ __launch_bounds__(256) void probe_gather_kernel(CacheDev c, const int
                 }
             }
         }
-        hits_acc += __builtin_popcount(hitmask);
-
-        // ---- misses: wave-aggregated append + per-set chain push
+        // ---- misses: stage positions in this wave's LDS slice, append 64 at a time
         if (missmask) {
-            uint32_t basem = 0;
-            if (lane == 0) basem = atomicAdd(c.miss_count + (gen & 1), (uint32_t)__builtin_popcount(missmask));
-            basem = __builtin_amdgcn_readfirstlane(basem);
-            if (lane < R && ((missmask >> lane) & 1)) {
-                const int64_t i_m = base + lane;
-                const uint64_t id = (uint64_t)idx[i_m];
-                const uint64_t set = set_of(c, id);
-                const uint32_t m = basem + __builtin_popcount(missmask & ((1u << lane) - 1));
-                const unsigned long long tag = ((unsigned long long)gen << 32) | (unsigned long long)(m + 1);
-                const unsigned long long prev = atomicExch(reinterpret_cast<unsigned long long*>(c.set_head + set), tag);
-                c.miss_pos[m] = (uint32_t)i_m;
-                c.miss_next[m] = ((uint32_t)(prev >> 32) == gen) ? (uint32_t)prev : 0u;
-            }
+            if (lane < R && ((missmask >> lane) & 1))
+                pend[npend + __builtin_popcount(missmask & ((1u << lane) - 1))] = (uint32_t)(base + lane);
+            npend += __builtin_popcount(missmask);
+            if (npend > kPendCap - R) wave_flush();
         }
-        if (badmask && lane == 0) atomicAdd(c.stats + 2, (unsigned long long)__builtin_popcount(badmask));
+        if (badmask && lane == 0) atomicAdd(c.miss_count + 2 + (gen & 1), (uint32_t)__builtin_popcount(badmask));
     }
-    if (lane == 0 && hits_acc) atomicAdd(c.stats + 0, hits_acc);
+    // block-level append
+    if (lane == 0) s_cnt[w_in_b] = npend;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (uint32_t q = 0; q < (blockDim.x >> 6); ++q) total += s_cnt[q];
+        s_base = total ? atomicAdd(c.miss_count + (gen & 1), total) : 0u;
+    }
+    __syncthreads();
+    uint32_t first = s_base;
+    for (int q = 0; q < w_in_b; ++q) first += s_cnt[q];
+    publish(first, npend);
 }
 
 // ---------------------------------------------------------------------------------------------------------- K2
 // Deterministic round-robin victim choice: rank of a miss = number of misses of the same set that precede it in the
 // batch.  (isolated_cache.h:197-210 executed in batch order.)
-__global__ __launch_bounds__(256) void rank_assign_kernel(CacheDev c, const int64_t* __restrict__ idx, uint32_t gen) {
+__global__ __launch_bounds__(256) void rank_assign_kernel(CacheDev c, const int64_t* __restrict__ idx, int64_t n, uint32_t gen) {
     const uint32_t M = c.miss_count[gen & 1];
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t t0 = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t0 == 0 && M) atomicAdd(c.stats + 1, (unsigned long long)M);
+    if (t0 == 0) { // hit / miss / rejected totals of the batch (isolated_cache.h:402-403,471-472)
+        const uint32_t bad = c.miss_count[2 + (gen & 1)];
+        c.stats[0] += (unsigned long long)(n - (int64_t)M - (int64_t)bad);
+        c.stats[1] += (unsigned long long)M;
+        c.stats[2] += (unsigned long long)bad;
+    }
     for (uint32_t m = t0; m < M; m += stride) {
         const uint32_t pos = c.miss_pos[m];
         const uint64_t id = (uint64_t)idx[pos];
@@ -260,7 +295,10 @@ __global__ __launch_bounds__(256) void cold_fill_kernel(CacheDev c, const int64_
     constexpr int R = G::R;
     const int lane = threadIdx.x & 63;
     const uint32_t M = c.miss_count[gen & 1];
-    if (blockIdx.x == 0 && threadIdx.x == 0) c.miss_count[(gen + 1) & 1] = 0; // next batch's counter
+    if (blockIdx.x == 0 && threadIdx.x == 0) { // next batch's counters
+        c.miss_count[(gen + 1) & 1] = 0;
+        c.miss_count[2 + ((gen + 1) & 1)] = 0;
+    }
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
     const int64_t n_chunks = ((int64_t)M + R - 1) / R;
@@ -639,13 +677,13 @@ int coala_cache_create(const coala_cache_config_t* cfg, coala_cache_t** out) {
         if ((rc = alloc((void**)&d.set_cnt, sets * 4))) break;
         if ((rc = alloc((void**)&d.color_meta, slots * 4))) break;
         if ((rc = alloc((void**)&d.set_head, sets * 8))) break;
-        if ((rc = alloc((void**)&d.miss_count, 2 * 4))) break;
+        if ((rc = alloc((void**)&d.miss_count, 4 * 4))) break;
         if ((rc = alloc((void**)&d.stats, 3 * 8))) break;
         if ((rc = alloc((void**)&d.lines, slots * (uint64_t)cd * 4))) break;
         if ((rc = alloc((void**)&h->route_bases, 65 * 8))) break;
         if (hipMemset(d.keys, 0xFF, slots * 8) != hipSuccess || hipMemset(d.set_cnt, 0, sets * 4) != hipSuccess ||
             hipMemset(d.color_meta, 0, slots * 4) != hipSuccess || hipMemset(d.set_head, 0, sets * 8) != hipSuccess ||
-            hipMemset(d.miss_count, 0, 8) != hipSuccess || hipMemset(d.stats, 0, 24) != hipSuccess) {
+            hipMemset(d.miss_count, 0, 16) != hipSuccess || hipMemset(d.stats, 0, 24) != hipSuccess) {
             rc = fail(COALA_EHIP, "hipMemset failed");
             break;
         }
@@ -729,13 +767,17 @@ static int read_feature_impl(coala_cache_t* h, float* out, const int64_t* idx, i
         constexpr int VEC = geo_vec(geo);
         using G = Geo<CD, VEC>;
         const int64_t chunks = (n + G::R - 1) / G::R;
+        // K1: one 16-wave block per CU (256 CUs); small batches get smaller blocks so that every CU still has work
+        const int k1_waves = chunks >= 256 * 16 ? 16 : (int)((chunks + 255) / 256 > 0 ? (chunks + 255) / 256 : 1);
+        const int k1_block = 64 * k1_waves;
+        const int k1_grid = grid_for(chunks, k1_waves, 256);
         {
             ProfScope ps(h, s, 0, (uint64_t)n);
-            hipLaunchKernelGGL((probe_gather_kernel<CD, VEC>), dim3(grid_for(chunks, 4, 256 * 16)), dim3(256), 0, s, d, idx, out, n, gen);
+            hipLaunchKernelGGL((probe_gather_kernel<CD, VEC>), dim3(k1_grid), dim3(k1_block), 0, s, d, idx, out, n, gen);
         }
         {
             ProfScope ps(h, s, 1, 0);
-            hipLaunchKernelGGL(rank_assign_kernel, dim3(grid_for((n + 255) / 256, 1, 1024)), dim3(256), 0, s, d, idx, gen);
+            hipLaunchKernelGGL(rank_assign_kernel, dim3(grid_for((n + 255) / 256, 1, 1024)), dim3(256), 0, s, d, idx, n, gen);
         }
         {
             ProfScope ps(h, s, 2, 0);

@@ -7,17 +7,18 @@
 //   cache_kernel.cu:59-77 / :93-111 / :38-57 read kernels, :79-91 split, :113-137 gather, :139-143 stats
 //   ssd_gnn_cache.cuh:84-109,227-360 host front-ends
 //
-// Design (DESIGN.md has the long form).  One call = one batch, three stream-ordered kernels:
-//   K1 probe_gather : a wave takes R rows (4, or 8 for 512-B lines).  One 16-B load per lane fetches the 32 tags of four
-//                     sets at once (16 lanes x 2 keys per set), two ballots find the matching way, hits are copied
-//                     HBM line -> output row with 16-B loads/stores, 4 rows in flight per wave.  Misses are appended to
-//                     a miss list (one wave-aggregated atomic per chunk) and pushed on a per-set chain whose head word is
-//                     tagged with the batch generation (no clearing pass).
-//   K2 rank_assign  : a thread per miss walks its set's chain and counts the misses that precede it in batch order: its
-//                     rank k.  way = (set_cnt + k) % 32 -- the reference's round robin, executed in batch order, for any
-//                     arrival order of the atomics.  Winners (last writer of a way) publish the key; colour counters move.
-//   K3 cold_fill    : a wave per missed row streams it from the cold tier (pinned host over PCIe, or HBM) into the output
-//                     row and, for winners, into the cache line.
+// Design (DESIGN.md has the long form).  One call = one batch, two stream-ordered kernels, no same-address atomics:
+//   K1 probe_gather : a wave takes R rows (4, or 8 for 512-B lines) per step of a grid-stride loop.  One 16-B load per
+//                     lane fetches the 32 tags of four sets at once (16 lanes x 2 keys per set), two ballots find the
+//                     matching way, hits are copied HBM line -> output row with nontemporal 16-B loads/stores, 4 rows in
+//                     flight per wave, with the next chunk's ids/tags prefetched behind them.  A miss is pushed on its
+//                     set's chain (atomicExch on the set's own head word, tagged with the batch generation so no clearing
+//                     pass is needed), bumps set_cnt, and marks row_state[position].
+//   K2 miss_fill    : same chunking.  For a missed row one lane walks the set's chain and counts the misses that precede
+//                     it in batch order: its rank k.  way = (set_cnt_before + k) % 32 -- the reference's round robin
+//                     executed in batch order, for any arrival order of the atomics.  The last writer of a way (the
+//                     "winner") publishes key, colour and line; every miss streams its row from the cold tier (pinned
+//                     host over PCIe, or HBM) into the output.
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
@@ -33,6 +34,7 @@
 namespace {
 
 constexpr uint64_t kEmptyKey = 0xFFFFFFFFFFFFFFFFull; // isolated_cache.h:552
+constexpr int kStatBlocks = 2048;                      // upper bound of K2's grid
 
 struct CacheDev {
     uint64_t* keys;        // [sets*32]
@@ -50,15 +52,11 @@ struct CacheDev {
     int32_t gshift;        // log2(n_gpus) if power of two else -1
     int32_t sshift;        // log2(num_sets) if power of two else -1
     uint32_t distributed;
-    // per-batch scratch
-    uint32_t* miss_count;  // [4]: [gen&1] misses of this batch, [2 + (gen&1)] rejected ids of this batch
-    uint64_t* set_head;    // [sets] : (gen << 32) | (miss index + 1)
-    uint32_t* miss_pos;    // [cap] position in the batch
-    uint32_t* miss_next;   // [cap] chain link (miss index + 1, 0 = end)
-    uint32_t* miss_slot;   // [cap] set*32 + way chosen by K2
-    uint32_t* miss_aux;    // [cap] bit0 winner, bit1 rank 0
-    uint32_t* miss_newcnt; // [cap] set_cnt after the batch (valid for rank 0)
-    unsigned long long* stats; // [0] hit [1] miss [2] range errors
+    // per-batch scratch, indexed by the row's POSITION in the batch (no compaction, no list counter)
+    uint8_t* row_state;    // [cap] 0 hit (or idle), 1 miss, 2 rejected id; K1 sets non-zero values, K2 clears them again
+    uint64_t* set_head;    // [sets] : (gen << 32) | (position + 1) of the most recently pushed miss of this set
+    uint32_t* miss_next;   // [cap] chain link (position + 1 of the previously pushed miss of the set, 0 = end)
+    unsigned long long* stats; // [kStatBlocks][2] running sums owned by K2's blocks: misses, rejected ids
 };
 
 __device__ __forceinline__ uint64_t set_of(const CacheDev& c, uint64_t id) {
@@ -99,71 +97,78 @@ struct Geo {
 };
 
 // ---------------------------------------------------------------------------------------------------------- K1
-// Probe R rows, copy the hits, enqueue the misses.
+// Probe R rows, copy the hits, mark the misses.  Software-pipelined over a wave's chunks: the ids of chunk k+2 and the
+// tag sets of chunk k+1 are requested while the rows of chunk k are in flight, so a wave never sits on the
+// id -> tag -> line dependency chain with nothing outstanding.  Lines and output rows are touched once per batch:
+// nontemporal loads/stores keep them from displacing the tag sets in L2.
+// Misses are NOT compacted: every per-miss record is indexed by the row's position in the batch, and the per-set chain
+// that K2 walks is pushed with one atomicExch on the set's own head word.  (Measured alternatives: a miss-list append
+// per chunk or per wave serialises at ~12 ns per same-address atomic -- 4096 waves = 49 us, as long as the whole hit
+// gather; a block-level append needs LDS staging and a trailing barrier and still costs 5-7 us.)
+constexpr int kK1Waves = 2; // waves per block (measured: 2048 x 128 threads beats 1024 x 256 and 256 x 1024 by 3-20 %)
+
+template <typename V> __device__ __forceinline__ V nt_load(const V* p) { return __builtin_nontemporal_load(p); }
+template <typename V> __device__ __forceinline__ void nt_store(V v, V* p) { __builtin_nontemporal_store(v, p); }
+
 template <int CD, int VEC>
-__global__ __launch_bounds__(1024) void probe_gather_kernel(CacheDev c, const int64_t* __restrict__ idx,
-                                                           float* __restrict__ out, int64_t n, uint32_t gen) {
+__global__ __launch_bounds__(64 * kK1Waves) void probe_gather_kernel(CacheDev c, const int64_t* __restrict__ idx,
+                                                                    float* __restrict__ out, int64_t n, uint32_t gen) {
     using G = Geo<CD, VEC>;
     using V = typename VecT<VEC>::type;
     constexpr int R = G::R;
-    constexpr int TSTEPS = (R + 3) / 4; // tag loads: four sets per wave-wide 16-B load
+    constexpr int TSTEPS = (R + 3) / 4; // tag loads: four sets per wave-wide 16-B load (16 lanes x 2 keys per set)
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
     const int64_t n_chunks = (n + R - 1) / R;
     const uint32_t nunits = c.dim / VEC; // accesses per output row
-    // Misses found by this wave wait in its LDS slice; the block appends them to the global miss list with ONE
-    // same-address atomic when it is done (256 blocks -> 256 atomics per batch).  Measured: an append per chunk, or
-    // even per wave, serialises at ~12 ns each on one address -- 4096 waves = 49 us, as long as the whole hit gather.
-    constexpr int kPendCap = 448;                    // per-wave staging entries (16 waves x 448 x 4 B = 28 KiB LDS)
-    __shared__ uint32_t s_pend[16][kPendCap];
-    __shared__ uint32_t s_cnt[16];
-    __shared__ uint32_t s_base;
-    const int w_in_b = threadIdx.x >> 6;
-    uint32_t* pend = s_pend[w_in_b];
-    uint32_t npend = 0;
-    auto publish = [&](uint32_t first_m, uint32_t count) { // lanes push `count` staged misses as list entries first_m..
-        for (uint32_t e = lane; e < count; e += 64) {
-            const uint32_t pos = pend[e];
-            const uint64_t id = (uint64_t)idx[pos];
-            const uint64_t set = set_of(c, id);
-            const uint32_t m = first_m + e;
-            const unsigned long long tag = ((unsigned long long)gen << 32) | (unsigned long long)(m + 1);
-            const unsigned long long prev = atomicExch(reinterpret_cast<unsigned long long*>(c.set_head + set), tag);
-            c.miss_pos[m] = pos;
-            c.miss_next[m] = ((uint32_t)(prev >> 32) == gen) ? (uint32_t)prev : 0u;
+
+    // probe state of one chunk: lane l looks at row q = 4t + l/16, keys 2(l%16), 2(l%16)+1 of that row's set
+    struct Ids { uint64_t id[TSTEPS]; bool valid[TSTEPS]; };
+    struct Tags { uint64_t id[TSTEPS]; uint64_t set[TSTEPS]; vu64x2 kk[TSTEPS]; bool ok[TSTEPS]; bool valid[TSTEPS]; };
+    auto load_ids = [&](int64_t chunk) {
+        Ids r;
+#pragma unroll
+        for (int t = 0; t < TSTEPS; ++t) {
+            const int q_l = t * 4 + (lane >> 4);
+            const int64_t i_l = chunk * R + q_l;
+            r.valid[t] = (chunk < n_chunks) && (q_l < R) && (i_l < n);
+            r.id[t] = r.valid[t] ? (uint64_t)idx[i_l] : 0;
         }
+        return r;
     };
-    auto wave_flush = [&]() { // overflow valve only: a wave's slice is full before the block is done
-        uint32_t basem = 0;
-        if (lane == 0) basem = atomicAdd(c.miss_count + (gen & 1), npend);
-        basem = __builtin_amdgcn_readfirstlane(basem);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        publish(basem, npend);
-        __builtin_amdgcn_wave_barrier();
-        npend = 0;
+    auto load_tags = [&](const Ids& ids) {
+        Tags r;
+#pragma unroll
+        for (int t = 0; t < TSTEPS; ++t) {
+            r.id[t] = ids.id[t];
+            r.valid[t] = ids.valid[t];
+            r.ok[t] = ids.valid[t] && ids.id[t] < c.num_rows;
+            r.set[t] = r.ok[t] ? set_of(c, ids.id[t]) : 0;
+            r.kk[t] = vu64x2{kEmptyKey, kEmptyKey};
+            if (r.ok[t]) r.kk[t] = *reinterpret_cast<const vu64x2*>(c.keys + r.set[t] * COALA_WAYS + (lane & 15) * 2);
+        }
+        return r;
     };
-    for (int64_t chunk = wave; chunk < n_chunks; chunk += n_waves) {
+
+    int64_t chunk = wave;
+    Ids ids_next = load_ids(chunk);
+    Tags tags = load_tags(ids_next);
+    ids_next = load_ids(chunk + n_waves);
+
+    for (; chunk < n_chunks; chunk += n_waves) {
         const int64_t base = chunk * R;
         uint32_t slot[R];       // wave-uniform: set*32 + way for hits
         uint32_t hitmask = 0;   // bit q: row q hits
         uint32_t missmask = 0;  // bit q: row q misses (valid, in range, no tag match)
         uint32_t badmask = 0;   // bit q: id outside [0, num_rows)
+        uint64_t my_set = 0;    // lane q < R: set of row q
 #pragma unroll
         for (int t = 0; t < TSTEPS; ++t) {
-            const int q_l = t * 4 + (lane >> 4);
-            const int64_t i_l = base + q_l;
-            const bool valid = (q_l < R) && (i_l < n);
-            const uint64_t id = valid ? (uint64_t)idx[i_l] : 0;
-            const bool ok = valid && id < c.num_rows;
-            const uint64_t set = ok ? set_of(c, id) : 0;
-            vu64x2 kk = {kEmptyKey, kEmptyKey};
-            if (ok) kk = *reinterpret_cast<const vu64x2*>(c.keys + set * COALA_WAYS + (lane & 15) * 2);
-            const uint64_t m0 = __ballot(ok && kk.x == id); // even ways
-            const uint64_t m1 = __ballot(ok && kk.y == id); // odd ways
-            const uint64_t okm = __ballot(ok);
-            const uint64_t vm = __ballot(valid);
+            const uint64_t m0 = __ballot(tags.ok[t] && tags.kk[t].x == tags.id[t]); // even ways
+            const uint64_t m1 = __ballot(tags.ok[t] && tags.kk[t].y == tags.id[t]); // odd ways
+            const uint64_t okm = __ballot(tags.ok[t]);
+            const uint64_t vm = __ballot(tags.valid[t]);
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) {
                 const int q = t * 4 + qq;
@@ -173,7 +178,7 @@ __global__ __launch_bounds__(1024) void probe_gather_kernel(CacheDev c, const in
                     const uint32_t mm = a | b;
                     const bool row_valid = (vm >> (16 * qq)) & 1;
                     const bool row_ok = (okm >> (16 * qq)) & 1;
-                    const uint64_t set_q = readlane64(set, 16 * qq);
+                    const uint64_t set_q = readlane64(tags.set[t], 16 * qq);
                     uint32_t way = 0;
                     if (mm) { // lowest matching way wins (isolated_cache.h:165-172)
                         const int j = __builtin_ctz(mm);
@@ -185,11 +190,22 @@ __global__ __launch_bounds__(1024) void probe_gather_kernel(CacheDev c, const in
                         badmask |= 1u << q;
                     }
                     slot[q] = (uint32_t)(set_q * COALA_WAYS) + way;
+                    if (lane == q) my_set = set_q;
                 }
             }
         }
+        // ---- misses: push the row on its set's chain (the old head comes back behind the row loads)
+        const bool i_miss = lane < R && ((missmask >> lane) & 1);
+        unsigned long long prev = 0;
+        if (i_miss) {
+            const unsigned long long tag = ((unsigned long long)gen << 32) | (unsigned long long)(base + lane + 1);
+            prev = atomicExch(reinterpret_cast<unsigned long long*>(c.set_head + my_set), tag);
+            atomicAdd(c.set_cnt + my_set, 1u); // isolated_cache.h:203 set_cnt_[set]++ (no return value needed)
+        }
+        // ids two chunks ahead (consumed by load_tags in the NEXT iteration: a full row round trip of slack)
+        const Ids ids_next2 = load_ids(chunk + 2 * n_waves);
 
-        // ---- hits: HBM line -> output row, PASSES row(-pair)s in flight
+        // ---- hits: HBM line -> registers, PASSES row(-pair)s in flight
         V val[G::PASSES][G::VPL];
         const int sub = (G::RPP == 2) ? (lane >> 5) : 0;
         const int l_in = lane & (G::LPR - 1);
@@ -202,9 +218,13 @@ __global__ __launch_bounds__(1024) void probe_gather_kernel(CacheDev c, const in
 #pragma unroll
             for (int v = 0; v < G::VPL; ++v) {
                 const uint32_t u = v * G::LPR + l_in;
-                if (h && u < nunits) val[p][v] = src[u];
+                if (h && u < nunits) val[p][v] = nt_load(src + u);
             }
         }
+        // ---- tag sets of the next chunk go out behind the row loads
+        tags = load_tags(ids_next);
+        ids_next = ids_next2;
+        // ---- registers -> output rows
 #pragma unroll
         for (int p = 0; p < G::PASSES; ++p) {
             const int q = p * G::RPP + sub;
@@ -215,144 +235,131 @@ __global__ __launch_bounds__(1024) void probe_gather_kernel(CacheDev c, const in
             for (int v = 0; v < G::VPL; ++v) {
                 const uint32_t u = v * G::LPR + l_in;
                 if (u < nunits) {
-                    if (h) dst[u] = val[p][v];
+                    if (h) nt_store(val[p][v], dst + u);
                     else if (bad) dst[u] = V(0.0f); // rejected id: zero row
                 }
             }
         }
-        // ---- misses: stage positions in this wave's LDS slice, append 64 at a time
-        if (missmask) {
-            if (lane < R && ((missmask >> lane) & 1))
-                pend[npend + __builtin_popcount(missmask & ((1u << lane) - 1))] = (uint32_t)(base + lane);
-            npend += __builtin_popcount(missmask);
-            if (npend > kPendCap - R) wave_flush();
+        // ---- verdict for K2: only rows that are not hits write anything (row_state is zero between batches)
+        if (i_miss) {
+            c.row_state[base + lane] = 1;
+            c.miss_next[base + lane] = ((uint32_t)(prev >> 32) == gen) ? (uint32_t)prev : 0u;
+        } else if (lane < R && ((badmask >> lane) & 1)) {
+            c.row_state[base + lane] = 2;
         }
-        if (badmask && lane == 0) atomicAdd(c.miss_count + 2 + (gen & 1), (uint32_t)__builtin_popcount(badmask));
     }
-    // block-level append
-    if (lane == 0) s_cnt[w_in_b] = npend;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t total = 0;
-        for (uint32_t q = 0; q < (blockDim.x >> 6); ++q) total += s_cnt[q];
-        s_base = total ? atomicAdd(c.miss_count + (gen & 1), total) : 0u;
-    }
-    __syncthreads();
-    uint32_t first = s_base;
-    for (int q = 0; q < w_in_b; ++q) first += s_cnt[q];
-    publish(first, npend);
 }
 
 // ---------------------------------------------------------------------------------------------------------- K2
-// Deterministic round-robin victim choice: rank of a miss = number of misses of the same set that precede it in the
-// batch.  (isolated_cache.h:197-210 executed in batch order.)
-__global__ __launch_bounds__(256) void rank_assign_kernel(CacheDev c, const int64_t* __restrict__ idx, int64_t n, uint32_t gen) {
-    const uint32_t M = c.miss_count[gen & 1];
-    const uint32_t stride = gridDim.x * blockDim.x;
-    const uint32_t t0 = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t0 == 0) { // hit / miss / rejected totals of the batch (isolated_cache.h:402-403,471-472)
-        const uint32_t bad = c.miss_count[2 + (gen & 1)];
-        c.stats[0] += (unsigned long long)(n - (int64_t)M - (int64_t)bad);
-        c.stats[1] += (unsigned long long)M;
-        c.stats[2] += (unsigned long long)bad;
-    }
-    for (uint32_t m = t0; m < M; m += stride) {
-        const uint32_t pos = c.miss_pos[m];
-        const uint64_t id = (uint64_t)idx[pos];
-        const uint64_t set = set_of(c, id);
-        uint32_t cur = (uint32_t)c.set_head[set]; // tagged with this generation by construction
-        uint32_t total = 0, rank = 0;
-        while (cur) {
-            const uint32_t mm = cur - 1;
-            const uint32_t p2 = c.miss_pos[mm];
-            ++total;
-            rank += (p2 < pos) ? 1u : 0u;
-            cur = c.miss_next[mm];
-        }
-        const uint32_t cnt0 = c.set_cnt[set];
-        const uint32_t way = (cnt0 + rank) & (COALA_WAYS - 1);
-        const uint32_t slot = (uint32_t)(set * COALA_WAYS) + way;
-        const bool winner = rank + COALA_WAYS >= total; // nobody later in the batch lands on this way
-        const bool first = rank < COALA_WAYS;            // evicts the pre-batch occupant
-        if (c.color_counters) {
-            if (first) atomicSub(c.color_counters + c.color_meta[slot], 1);      // isolated_cache.h:427-429
-            if (winner) atomicAdd(c.color_counters + c.node_color[id], 1);       // isolated_cache.h:437-441
-        }
-        if (winner) c.keys[slot] = id;                                           // isolated_cache.h:434
-        c.miss_slot[m] = slot;
-        c.miss_aux[m] = (winner ? 1u : 0u) | (rank == 0 ? 2u : 0u);
-        c.miss_newcnt[m] = cnt0 + total;
-    }
+// Rank + fill.  isolated_cache.h:197-210 (round robin in batch order), :417-474 (miss path), :323-331 (cold read).
+// Hazard-free in ONE kernel because K1 already advanced set_cnt: set_cnt_before = set_cnt - (misses of the set), every
+// way touched in this batch has exactly one winner, and only winners touch keys / color_meta / lines.
+__device__ __forceinline__ uint64_t shfl64(uint64_t v, int src) {
+    const uint32_t lo = __shfl((int)(uint32_t)v, src), hi = __shfl((int)(uint32_t)(v >> 32), src);
+    return ((uint64_t)hi << 32) | lo;
 }
 
-// ---------------------------------------------------------------------------------------------------------- K3
-// Cold tier -> output row (+ cache line for winners).  isolated_cache.h:323-331,449-465.
 template <int CD, int VEC>
-__global__ __launch_bounds__(256) void cold_fill_kernel(CacheDev c, const int64_t* __restrict__ idx, float* __restrict__ out,
-                                                        uint32_t gen) {
+__global__ __launch_bounds__(256) void miss_fill_kernel(CacheDev c, const int64_t* __restrict__ idx, float* __restrict__ out,
+                                                        int64_t n) {
     using G = Geo<CD, VEC>;
     using V = typename VecT<VEC>::type;
     constexpr int R = G::R;
     const int lane = threadIdx.x & 63;
-    const uint32_t M = c.miss_count[gen & 1];
-    if (blockIdx.x == 0 && threadIdx.x == 0) { // next batch's counters
-        c.miss_count[(gen + 1) & 1] = 0;
-        c.miss_count[2 + ((gen + 1) & 1)] = 0;
-    }
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
-    const int64_t n_chunks = ((int64_t)M + R - 1) / R;
+    const int64_t n_chunks = (n + R - 1) / R;
     const uint32_t nunits = c.dim / VEC;
     const int sub = (G::RPP == 2) ? (lane >> 5) : 0;
     const int l_in = lane & (G::LPR - 1);
+    uint32_t my_miss = 0, my_bad = 0;
 
     for (int64_t chunk = wave; chunk < n_chunks; chunk += n_waves) {
         const int64_t base = chunk * R;
+        const int64_t pos_l = base + lane;
+        const uint8_t st = (lane < R && pos_l < n) ? c.row_state[pos_l] : (uint8_t)0;
+        const uint64_t live_mask = __ballot(st == 1);
+        if (st) c.row_state[pos_l] = 0; // leave the array clean for the next batch
+        my_miss += (st == 1);
+        my_bad += (st == 2);
+        if (!live_mask) continue;
+        // ---- lanes q < R holding a miss: rank it inside its set and pick the way
+        uint32_t slot_l = 0, win_l = 0;
+        uint64_t id_l = 0;
+        if (st == 1) {
+            id_l = (uint64_t)idx[pos_l];
+            const uint64_t set = set_of(c, id_l);
+            uint32_t cur = (uint32_t)c.set_head[set]; // tagged with this generation: this row was pushed on it by K1
+            uint32_t total = 0, rank = 0;
+            while (cur) {
+                const uint32_t p2 = cur - 1;
+                ++total;
+                rank += (p2 < (uint32_t)pos_l) ? 1u : 0u;
+                cur = c.miss_next[p2];
+            }
+            const uint32_t cnt0 = c.set_cnt[set] - total;                       // value before this batch
+            const uint32_t way = (cnt0 + rank) & (COALA_WAYS - 1);              // isolated_cache.h:203
+            slot_l = (uint32_t)(set * COALA_WAYS) + way;
+            win_l = (rank + COALA_WAYS >= total) ? 1u : 0u;                     // nobody later in the batch lands here
+            if (win_l) {
+                c.keys[slot_l] = id_l;                                          // isolated_cache.h:434
+                if (c.color_counters) {
+                    // the pre-batch occupant leaves (:427-429), the winner enters (:437-441); rows that were inserted and
+                    // overwritten again inside this batch cancel out
+                    const int32_t col = c.node_color[id_l];
+                    atomicSub(c.color_counters + c.color_meta[slot_l], 1);
+                    atomicAdd(c.color_counters + col, 1);
+                    c.color_meta[slot_l] = (uint32_t)col;
+                }
+            }
+        }
+        // ---- every lane learns the rows of its pass
         V val[G::PASSES][G::VPL];
-        uint32_t pos[G::PASSES], slot_[G::PASSES], aux[G::PASSES], ncnt[G::PASSES];
+        uint32_t slot_[G::PASSES];
         uint64_t id[G::PASSES];
-        bool live[G::PASSES];
+        bool live[G::PASSES], winner[G::PASSES];
 #pragma unroll
         for (int p = 0; p < G::PASSES; ++p) {
-            const int64_t m = base + p * G::RPP + sub;
-            live[p] = m < (int64_t)M;
-            pos[p] = slot_[p] = aux[p] = ncnt[p] = 0;
-            id[p] = 0;
-            if (live[p]) {
-                pos[p] = c.miss_pos[m];
-                slot_[p] = c.miss_slot[m];
-                aux[p] = c.miss_aux[m];
-                ncnt[p] = c.miss_newcnt[m];
-                id[p] = (uint64_t)idx[pos[p]];
-            }
+            const int q = p * G::RPP + sub;
+            live[p] = (live_mask >> q) & 1;
+            slot_[p] = (uint32_t)__shfl((int)slot_l, q);
+            winner[p] = __shfl((int)win_l, q) != 0;
+            id[p] = shfl64(id_l, q);
         }
 #pragma unroll
         for (int p = 0; p < G::PASSES; ++p) {
-            const V* src = reinterpret_cast<const V*>(c.cold + id[p] * (uint64_t)c.dim); // host stride = dim
+            const V* src = reinterpret_cast<const V*>(c.cold + id[p] * (uint64_t)c.dim); // cold stride = dim
 #pragma unroll
             for (int v = 0; v < G::VPL; ++v) {
                 const uint32_t u = v * G::LPR + l_in;
-                if (live[p] && u < nunits) val[p][v] = src[u];
+                if (live[p] && u < nunits) val[p][v] = nt_load(src + u);
             }
         }
 #pragma unroll
         for (int p = 0; p < G::PASSES; ++p) {
-            V* dst = reinterpret_cast<V*>(out + (uint64_t)pos[p] * c.dim);
+            const int q = p * G::RPP + sub;
+            V* dst = reinterpret_cast<V*>(out + (uint64_t)(base + q) * c.dim);
             V* line = reinterpret_cast<V*>(c.lines + (uint64_t)slot_[p] * CD);
-            const bool winner = aux[p] & 1u;
 #pragma unroll
             for (int v = 0; v < G::VPL; ++v) {
                 const uint32_t u = v * G::LPR + l_in;
                 if (live[p] && u < nunits) {
-                    dst[u] = val[p][v];
-                    if (winner) line[u] = val[p][v];
+                    nt_store(val[p][v], dst + u);
+                    if (winner[p]) nt_store(val[p][v], line + u);
                 }
             }
-            if (live[p] && l_in == 0) {
-                if (winner && c.node_color) c.color_meta[slot_[p]] = (uint32_t)c.node_color[id[p]]; // isolated_cache.h:438
-                if (aux[p] & 2u) c.set_cnt[slot_[p] / COALA_WAYS] = ncnt[p];                         // isolated_cache.h:203
-            }
         }
+    }
+    // miss / rejected totals (isolated_cache.h:471-472): a running sum per block, owned by that block -- no atomics
+    __shared__ uint32_t s_m[256 / 64], s_b[256 / 64];
+    for (int off = 32; off > 0; off >>= 1) { my_miss += __shfl_down(my_miss, off); my_bad += __shfl_down(my_bad, off); }
+    if (lane == 0) { s_m[threadIdx.x >> 6] = my_miss; s_b[threadIdx.x >> 6] = my_bad; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t m = 0, b = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { m += s_m[w]; b += s_b[w]; }
+        if (m) c.stats[2 * blockIdx.x] += m;
+        if (b) c.stats[2 * blockIdx.x + 1] += b;
     }
 }
 
@@ -383,7 +390,7 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(float* __restrict__ o
 #pragma unroll
             for (int v = 0; v < G::VPL; ++v) {
                 const uint32_t u = v * G::LPR + l_in;
-                if (d[p] >= 0 && u < nunits) val[p][v] = s[u];
+                if (d[p] >= 0 && u < nunits) val[p][v] = nt_load(s + u);
             }
         }
 #pragma unroll
@@ -392,7 +399,7 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(float* __restrict__ o
 #pragma unroll
             for (int v = 0; v < G::VPL; ++v) {
                 const uint32_t u = v * G::LPR + l_in;
-                if (d[p] >= 0 && u < nunits) t[u] = val[p][v];
+                if (d[p] >= 0 && u < nunits) nt_store(val[p][v], t + u);
             }
         }
     }
@@ -521,6 +528,7 @@ struct coala_cache {
     std::vector<hipEvent_t> ev_pool;
     coala_cache_profile_t prof{};
     uint64_t table_bytes = 0;
+    uint64_t rows_total = 0;              // rows submitted since the last stats reset (hits = rows - misses - rejected)
     uint64_t cum_hit = 0, cum_miss = 0;   // totals folded in whenever coala_cache_stats resets the device counters
     uint64_t prof_hit0 = 0, prof_miss0 = 0; // totals at the last profile reset
 };
@@ -542,12 +550,13 @@ int ensure_scratch(coala_cache* h, uint64_t n, hipStream_t s) {
     HIPCHK(hipStreamSynchronize(s));
     uint64_t cap = h->cap ? h->cap : 1024;
     while (cap < n) cap *= 2;
-    uint32_t** arrs[] = {&h->d.miss_pos, &h->d.miss_next, &h->d.miss_slot, &h->d.miss_aux, &h->d.miss_newcnt};
-    for (auto a : arrs) {
-        if (*a) HIPCHK(hipFree(*a));
-        *a = nullptr;
-        HIPCHK(hipMalloc((void**)a, cap * sizeof(uint32_t)));
-    }
+    if (h->d.miss_next) HIPCHK(hipFree(h->d.miss_next));
+    h->d.miss_next = nullptr;
+    HIPCHK(hipMalloc((void**)&h->d.miss_next, cap * sizeof(uint32_t)));
+    if (h->d.row_state) HIPCHK(hipFree(h->d.row_state));
+    h->d.row_state = nullptr;
+    HIPCHK(hipMalloc((void**)&h->d.row_state, cap));
+    HIPCHK(hipMemset(h->d.row_state, 0, cap)); // K1 marks non-hits, K2 clears them again
     h->cap = cap;
     return COALA_OK;
 }
@@ -677,13 +686,12 @@ int coala_cache_create(const coala_cache_config_t* cfg, coala_cache_t** out) {
         if ((rc = alloc((void**)&d.set_cnt, sets * 4))) break;
         if ((rc = alloc((void**)&d.color_meta, slots * 4))) break;
         if ((rc = alloc((void**)&d.set_head, sets * 8))) break;
-        if ((rc = alloc((void**)&d.miss_count, 4 * 4))) break;
-        if ((rc = alloc((void**)&d.stats, 3 * 8))) break;
+        if ((rc = alloc((void**)&d.stats, kStatBlocks * 2 * 8))) break;
         if ((rc = alloc((void**)&d.lines, slots * (uint64_t)cd * 4))) break;
         if ((rc = alloc((void**)&h->route_bases, 65 * 8))) break;
         if (hipMemset(d.keys, 0xFF, slots * 8) != hipSuccess || hipMemset(d.set_cnt, 0, sets * 4) != hipSuccess ||
             hipMemset(d.color_meta, 0, slots * 4) != hipSuccess || hipMemset(d.set_head, 0, sets * 8) != hipSuccess ||
-            hipMemset(d.miss_count, 0, 16) != hipSuccess || hipMemset(d.stats, 0, 24) != hipSuccess) {
+            hipMemset(d.stats, 0, kStatBlocks * 2 * 8) != hipSuccess) {
             rc = fail(COALA_EHIP, "hipMemset failed");
             break;
         }
@@ -726,8 +734,8 @@ int coala_cache_destroy(coala_cache_t* h) {
     drain_events(h);
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
     CacheDev& d = h->d;
-    void* ptrs[] = {d.keys, d.set_cnt, d.color_meta, d.set_head, d.miss_count, d.stats, d.lines, d.color_counters,
-                    h->node_color_dev, d.miss_pos, d.miss_next, d.miss_slot, d.miss_aux, d.miss_newcnt,
+    void* ptrs[] = {d.keys, d.set_cnt, d.color_meta, d.set_head, d.row_state, d.stats, d.lines, d.color_counters,
+                    h->node_color_dev, d.miss_next,
                     h->wave_counts, h->route_bases};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -767,22 +775,17 @@ static int read_feature_impl(coala_cache_t* h, float* out, const int64_t* idx, i
         constexpr int VEC = geo_vec(geo);
         using G = Geo<CD, VEC>;
         const int64_t chunks = (n + G::R - 1) / G::R;
-        // K1: one 16-wave block per CU (256 CUs); small batches get smaller blocks so that every CU still has work
-        const int k1_waves = chunks >= 256 * 16 ? 16 : (int)((chunks + 255) / 256 > 0 ? (chunks + 255) / 256 : 1);
-        const int k1_block = 64 * k1_waves;
-        const int k1_grid = grid_for(chunks, k1_waves, 256);
+        // K1: 2-wave blocks, 16 waves per CU resident (4 per SIMD at ~118 VGPRs); grid-stride over the chunks
         {
             ProfScope ps(h, s, 0, (uint64_t)n);
-            hipLaunchKernelGGL((probe_gather_kernel<CD, VEC>), dim3(k1_grid), dim3(k1_block), 0, s, d, idx, out, n, gen);
-        }
-        {
-            ProfScope ps(h, s, 1, 0);
-            hipLaunchKernelGGL(rank_assign_kernel, dim3(grid_for((n + 255) / 256, 1, 1024)), dim3(256), 0, s, d, idx, n, gen);
+            hipLaunchKernelGGL((probe_gather_kernel<CD, VEC>), dim3(grid_for(chunks, kK1Waves, 256 * 8)), dim3(64 * kK1Waves), 0, s, d, idx,
+                               out, n, gen);
         }
         {
             ProfScope ps(h, s, 2, 0);
-            hipLaunchKernelGGL((cold_fill_kernel<CD, VEC>), dim3(grid_for(chunks, 4, 256 * 8)), dim3(256), 0, s, d, idx, out, gen);
+            hipLaunchKernelGGL((miss_fill_kernel<CD, VEC>), dim3(grid_for(chunks, 4, kStatBlocks)), dim3(256), 0, s, d, idx, out, n);
         }
+        h->rows_total += (uint64_t)n;
         return COALA_OK;
     });
     if (rc) return rc;
@@ -866,18 +869,29 @@ int coala_cache_color_counts(coala_cache_t* h, int32_t* dst, int32_t n_entries, 
     return COALA_OK;
 }
 
+static int read_stats(coala_cache_t* h, hipStream_t s, uint64_t* hit, uint64_t* miss, uint64_t* bad, bool reset) {
+    std::vector<unsigned long long> part((size_t)kStatBlocks * 2);
+    HIPCHK(hipMemcpyAsync(part.data(), h->d.stats, part.size() * 8, hipMemcpyDeviceToHost, s));
+    if (reset) HIPCHK(hipMemsetAsync(h->d.stats, 0, part.size() * 8, s));
+    HIPCHK(hipStreamSynchronize(s));
+    uint64_t m = 0, b = 0;
+    for (int i = 0; i < kStatBlocks; ++i) { m += part[2 * i]; b += part[2 * i + 1]; }
+    *miss = m;
+    *bad = b;
+    *hit = h->rows_total - m - b;
+    if (reset) { h->cum_hit += *hit; h->cum_miss += m; h->rows_total = 0; }
+    return COALA_OK;
+}
+
 int coala_cache_stats(coala_cache_t* h, uint64_t* hit, uint64_t* miss, uint64_t* range_errors, int reset, void* stream) {
     if (!h) return fail(COALA_EINVAL, "null handle");
-    hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipSetDevice(h->cfg.device));
-    unsigned long long v[3];
-    HIPCHK(hipMemcpyAsync(v, h->d.stats, sizeof(v), hipMemcpyDeviceToHost, s));
-    if (reset) HIPCHK(hipMemsetAsync(h->d.stats, 0, sizeof(v), s));
-    HIPCHK(hipStreamSynchronize(s));
-    if (reset) { h->cum_hit += v[0]; h->cum_miss += v[1]; }
-    if (hit) *hit = v[0];
-    if (miss) *miss = v[1];
-    if (range_errors) *range_errors = v[2];
+    uint64_t v0, v1, v2;
+    int rc = read_stats(h, (hipStream_t)stream, &v0, &v1, &v2, reset != 0);
+    if (rc) return rc;
+    if (hit) *hit = v0;
+    if (miss) *miss = v1;
+    if (range_errors) *range_errors = v2;
     return COALA_OK;
 }
 
@@ -897,9 +911,10 @@ int coala_cache_profile(coala_cache_t* h, coala_cache_profile_t* out, int reset)
     if (!h || !out) return fail(COALA_EINVAL, "null argument");
     HIPCHK(hipSetDevice(h->cfg.device));
     drain_events(h);
-    unsigned long long v[3];
-    HIPCHK(hipMemcpy(v, h->d.stats, sizeof(v), hipMemcpyDeviceToHost));
-    const uint64_t th = h->cum_hit + v[0], tm = h->cum_miss + v[1];
+    uint64_t v0, v1, v2;
+    int rc = read_stats(h, nullptr, &v0, &v1, &v2, false);
+    if (rc) return rc;
+    const uint64_t th = h->cum_hit + v0, tm = h->cum_miss + v1;
     h->prof.gather_hits = th - h->prof_hit0;
     h->prof.fill_rows = tm - h->prof_miss0;
     *out = h->prof;

@@ -1,0 +1,176 @@
+// tools/k1_bench.hip -- A/B harness for the probe+gather kernel (development tool, not part of the product or tests).
+// Includes the product source so that the kernels in its anonymous namespace can be launched with other grids and
+// compared with experimental variants in one process (interleaved timing, hipEvents).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude tools/k1_bench.hip coala-gnn_amd/csrc/coala_host.cpp -o tools/k1_bench -lrt
+//   tools/k1_bench [rows_in_table] [n] [dim] [hit_percent]
+#include "../coala-gnn_amd/csrc/coala_cache.hip"
+
+#include <algorithm>
+#include <functional>
+#include <numeric>
+#include <random>
+#include <string>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
+
+namespace {
+
+// ---------------------------------------------------------------- experimental variant: software-pipelined, optional nt
+template <int CD, bool NT, int PASSES_>
+__global__ __launch_bounds__(1024) void probe_gather_v2(CacheDev c, const int64_t* __restrict__ idx, float* __restrict__ out,
+                                                        int64_t n, uint32_t gen) {
+    // all-hit fast path only (no miss bookkeeping): measures what the data movement alone can reach
+    constexpr int R = PASSES_;
+    using V = vfloat4;
+    constexpr int VPL = CD / 4 / 64;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t n_chunks = (n + R - 1) / R;
+    int64_t chunk = wave;
+    if (chunk >= n_chunks) return;
+    // prologue: ids + tags of the first chunk
+    auto load_id = [&](int64_t ch) -> uint64_t {
+        const int64_t i_l = ch * R + (lane >> 4);
+        return ((lane >> 4) < R && i_l < n) ? (uint64_t)idx[i_l] : 0xFFFFFFFFFFFFFFFFull;
+    };
+    uint64_t id = load_id(chunk);
+    uint64_t id_next = (chunk + n_waves < n_chunks) ? load_id(chunk + n_waves) : 0xFFFFFFFFFFFFFFFFull;
+    bool ok = id < c.num_rows;
+    uint64_t set = ok ? set_of(c, id) : 0;
+    vu64x2 kk = {kEmptyKey, kEmptyKey};
+    if (ok) kk = *reinterpret_cast<const vu64x2*>(c.keys + set * COALA_WAYS + (lane & 15) * 2);
+    for (; chunk < n_chunks; chunk += n_waves) {
+        const int64_t base = chunk * R;
+        const uint64_t m0 = __ballot(ok && kk.x == id);
+        const uint64_t m1 = __ballot(ok && kk.y == id);
+        uint32_t slot[R];
+        uint32_t hitmask = 0;
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const uint32_t a = (uint32_t)(m0 >> (16 * q)) & 0xFFFFu, b = (uint32_t)(m1 >> (16 * q)) & 0xFFFFu, mm = a | b;
+            const uint64_t set_q = readlane64(set, 16 * q);
+            uint32_t way = 0;
+            if (mm) { const int j = __builtin_ctz(mm); way = 2 * j + (((a >> j) & 1) ? 0 : 1); hitmask |= 1u << q; }
+            slot[q] = (uint32_t)(set_q * COALA_WAYS) + way;
+        }
+        // id two chunks ahead
+        const int64_t ch2 = chunk + 2 * n_waves;
+        uint64_t id_next2 = (ch2 < n_chunks) ? load_id(ch2) : 0xFFFFFFFFFFFFFFFFull;
+        V val[R][VPL];
+#pragma unroll
+        for (int p = 0; p < R; ++p) {
+            const V* src = reinterpret_cast<const V*>(c.lines + (uint64_t)slot[p] * CD);
+#pragma unroll
+            for (int v = 0; v < VPL; ++v)
+                if ((hitmask >> p) & 1) val[p][v] = NT ? __builtin_nontemporal_load(src + v * 64 + lane) : src[v * 64 + lane];
+        }
+        // tags of the next chunk (its id was requested one iteration ago)
+        id = id_next;
+        id_next = id_next2;
+        ok = id < c.num_rows;
+        set = ok ? set_of(c, id) : 0;
+        kk = vu64x2{kEmptyKey, kEmptyKey};
+        if (ok) kk = *reinterpret_cast<const vu64x2*>(c.keys + set * COALA_WAYS + (lane & 15) * 2);
+#pragma unroll
+        for (int p = 0; p < R; ++p) {
+            V* dst = reinterpret_cast<V*>(out + (base + p) * (int64_t)c.dim);
+#pragma unroll
+            for (int v = 0; v < VPL; ++v)
+                if ((hitmask >> p) & 1) {
+                    if (NT) __builtin_nontemporal_store(val[p][v], dst + v * 64 + lane);
+                    else dst[v * 64 + lane] = val[p][v];
+                }
+        }
+    }
+}
+
+struct Variant {
+    std::string name;
+    std::function<void(hipStream_t)> launch;
+};
+
+} // namespace
+
+#include <functional>
+
+int main(int argc, char** argv) {
+    const uint64_t rows = argc > 1 ? strtoull(argv[1], 0, 10) : 2000000ull;
+    const int64_t n = argc > 2 ? atoll(argv[2]) : 36864;
+    const int dim = argc > 3 ? atoi(argv[3]) : 1024;
+    const int hit_pct = argc > 4 ? atoi(argv[4]) : 100;
+    CK(hipSetDevice(0));
+    float* cold = nullptr;
+    CK(hipMalloc(&cold, rows * (uint64_t)dim * 4));
+    CK(hipMemset(cold, 0x3c, rows * (uint64_t)dim * 4));
+    coala_cache_config_t cfg{};
+    cfg.device = 0; cfg.dim = dim; cfg.cache_mb = 4096; cfg.n_gpus = 1; cfg.rank = 0; cfg.flags = COALA_FLAG_SYNC;
+    cfg.cold_table = cold; cfg.num_rows = rows; cfg.max_batch = (uint64_t)n;
+    coala_cache_t* h = nullptr;
+    if (coala_cache_create(&cfg, &h)) { printf("create failed: %s\n", coala_last_error()); return 1; }
+    std::vector<int64_t> perm(rows);
+    std::iota(perm.begin(), perm.end(), 0);
+    std::mt19937_64 rng(1);
+    std::shuffle(perm.begin(), perm.end(), rng);
+    std::vector<int64_t> warm(perm.begin(), perm.begin() + n);
+    std::vector<int64_t> ids = warm;
+    const int64_t n_hit = n * hit_pct / 100;
+    for (int64_t i = n_hit; i < n; ++i) ids[i] = perm[n + i]; // never cached
+    std::shuffle(ids.begin(), ids.end(), rng);
+    int64_t *d_warm, *d_ids;
+    float* out;
+    CK(hipMalloc(&d_warm, n * 8)); CK(hipMalloc(&d_ids, n * 8)); CK(hipMalloc(&out, (uint64_t)n * dim * 4));
+    CK(hipMemcpy(d_warm, warm.data(), n * 8, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_ids, ids.data(), n * 8, hipMemcpyHostToDevice));
+    if (coala_cache_read_feature(h, out, d_warm, n, nullptr)) { printf("warm failed: %s\n", coala_last_error()); return 1; }
+    CK(hipDeviceSynchronize());
+    hipStream_t st;
+    CK(hipStreamCreate(&st));
+    const double alg_bytes = (double)n * 264.0 + (double)n_hit * 2.0 * dim * 4.0;
+
+    std::vector<Variant> vs;
+    auto add_prod = [&](int grid, int block) {
+        vs.push_back({"prod g" + std::to_string(grid) + " b" + std::to_string(block), [=](hipStream_t s) {
+            // all-hit runs never touch the miss structures; with misses the product path (read_feature) is timed instead
+            if (dim == 1024) hipLaunchKernelGGL((probe_gather_kernel<1024, 4>), dim3(grid), dim3(block), 0, s, h->d, d_ids, out, n, 1u);
+            else if (dim == 128) hipLaunchKernelGGL((probe_gather_kernel<128, 4>), dim3(grid), dim3(block), 0, s, h->d, d_ids, out, n, 1u);
+        }});
+    };
+    if (hit_pct == 100) {
+        add_prod(1024, 256); add_prod(2048, 256); add_prod(1280, 256); add_prod(2048, 128); add_prod(2560, 128); add_prod(768, 256); add_prod(4096, 64); add_prod(1152, 256);
+        if (dim == 1024) {
+            auto add_v2 = [&](const char* nm, auto kern, int grid, int block) {
+                vs.push_back({std::string(nm) + " g" + std::to_string(grid) + " b" + std::to_string(block),
+                              [=](hipStream_t s) { hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, s, h->d, d_ids, out, n, 1u); }});
+            };
+            for (auto gb : {std::pair<int, int>{512, 512}, {1024, 256}}) {
+                add_v2("v2 pipe  R4", probe_gather_v2<1024, false, 4>, gb.first, gb.second);
+                add_v2("v2 pipe+nt R4", probe_gather_v2<1024, true, 4>, gb.first, gb.second);
+                add_v2("v2 pipe  R2", probe_gather_v2<1024, false, 2>, gb.first * 2, gb.second);
+                add_v2("v2 pipe+nt R2", probe_gather_v2<1024, true, 2>, gb.first * 2, gb.second);
+            }
+        }
+    }
+    vs.push_back({"product read_feature (K1+K2+K3)", [=](hipStream_t s) { coala_cache_read_feature(h, out, d_ids, n, s); }});
+
+    const int reps = 30;
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    std::vector<double> best(vs.size(), 1e30), sum(vs.size(), 0);
+    for (int r = 0; r < reps + 2; ++r)
+        for (size_t v = 0; v < vs.size(); ++v) { // interleaved A/B
+            CK(hipEventRecord(a, st));
+            vs[v].launch(st);
+            CK(hipEventRecord(b, st));
+            CK(hipEventSynchronize(b));
+            float ms;
+            CK(hipEventElapsedTime(&ms, a, b));
+            if (r >= 2) { best[v] = std::min(best[v], (double)ms); sum[v] += ms; }
+        }
+    CK(hipGetLastError());
+    printf("n=%lld dim=%d hit%%=%d alg_bytes=%.1f MB\n", (long long)n, dim, hit_pct, alg_bytes / 1e6);
+    for (size_t v = 0; v < vs.size(); ++v)
+        printf("%-40s avg %8.2f us  min %8.2f us   %7.1f GB/s (avg)  %5.1f%% of 8 TB/s\n", vs[v].name.c_str(), sum[v] / reps * 1e3,
+               best[v] * 1e3, alg_bytes / (sum[v] / reps * 1e-3) / 1e9, alg_bytes / (sum[v] / reps * 1e-3) / 1e9 / 80.0);
+    return 0;
+}

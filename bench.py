@@ -76,9 +76,9 @@ def main():
     import __graft_entry__ as entry
     if rank == 0:
         entry._load_build_module().build_lib()
-    from COALA_GNN import MPI_Comm_Manager, Shared_UVA_Tensor_Manager
+    from COALA_GNN import MPI_Comm_Manager
     from COALA_GNN.COALA_GNN_Manager import COALA_GNN_Manager
-    from COALA_GNN.synthetic import PinnedFeatureTable, fill_table, powerlaw_csc
+    from COALA_GNN.synthetic import PinnedFeatureTable, fill_table, fill_table_partition, powerlaw_csc
     from COALA_GNN.sampler import NeighborSampler
 
     backend = args.backend or ("isolated" if world == 1 else "nccl")
@@ -88,26 +88,23 @@ def main():
     # ---------------------------------------------------------------- cold tier: fp32 [rows, dim] in pinned host memory
     t0 = time.time()
     nbytes = args.rows * args.dim * 4
-    if world == 1:
+    cold_partitioned = False
+    if world == 1 or backend == "isolated":
+        # the whole table, private to this rank (an isolated cache may read any row)
         table = PinnedFeatureTable(args.rows, args.dim, local_rank)
         fill_table(table.cpu_tensor, args.seed, device=device)
-        sim_ptr_owner = table
         host_array = table.array
     else:
-        shm = Shared_UVA_Tensor_Manager(comm, f"/coala_bench_feat_{os.environ.get('MASTER_PORT', '0')}", nbytes)
-        host_array = shm.get_host_array(np.float32, (args.rows, args.dim))
-        lo = args.rows * comm.local_rank // comm.local_size
-        hi = args.rows * (comm.local_rank + 1) // comm.local_size
-        fill_table(torch.from_numpy(host_array[lo:hi]), args.seed, device=device, row0=lo)
-        comm.local_comm.Barrier()
-
-        class _Alias:  # what COALA_GNN_Manager needs from sim_buf: data_ptr() and shape
-            shape = (args.rows, args.dim)
-
-            @staticmethod
-            def data_ptr():
-                return shm.device_ptr
-        sim_ptr_owner = _Alias()
+        # owner-partitioned cold tier: rank r pins only the rows it owns (id % world == r), next to its own PCIe link.
+        # (The reference maps ONE shared copy into every GPU: shared_UVA.cuh:42-100, available here as
+        # Shared_UVA_Tensor_Manager; an owner of the partitioned cache never reads another owner's rows.)
+        local_rows = (args.rows + world - 1) // world
+        table = PinnedFeatureTable(local_rows, args.dim, local_rank)
+        fill_table_partition(table.cpu_tensor, args.seed, comm.local_rank, world, device=device)
+        host_array = None
+        cold_partitioned = True
+        nbytes = local_rows * args.dim * 4
+    sim_ptr_owner = table
     log(f"cold table {nbytes / 1e9:.2f} GB pinned + filled in {time.time() - t0:.1f}s")
 
     # ---------------------------------------------------------------- graph + train ids
@@ -124,7 +121,7 @@ def main():
     manager = COALA_GNN_Manager(node_distributor=None, num_ssds=1, page_size=args.dim * 4, num_elems=1024, ssd_read_offset=0,
                                 cache_size=args.cache_mb, batch_size=args.batch, fan_out=fanout, dim=args.dim,
                                 MPI_comm_manager=comm, device=device, cache_backend=backend, sim_buf=sim_ptr_owner,
-                                num_rows=args.rows, profile=True)
+                                num_rows=args.rows, profile=True, cold_partitioned=cold_partitioned)
     cache = manager.COALA_GNN_Cache
     max_rows = manager.max_sample_size
 
@@ -218,7 +215,8 @@ def main():
                                    f"mode={args.mode}",
                        "rows_per_step_per_gpu": round(rows_all / world / args.steps, 1),
                        "hit_ratio": round(hit_all / max(hit_all + miss_all, 1.0), 4),
-                       "cache_backend": backend, "prewarm_steps": args.prewarm,
+                       "cache_backend": backend, "cold_tier": "pinned host, owner-partitioned" if cold_partitioned else "pinned host",
+                       "prewarm_steps": args.prewarm,
                        "steps_per_epoch": steps_per_epoch,
                        "epoch_time_s_fetch_only_extrapolated": round(ms_per_step * steps_per_epoch / 1e3, 2)},
             "roofline": roofline,

@@ -103,7 +103,7 @@ class AllToAllExchange(object):
 class COALA_GNN_Manager(object):
     def __init__(self, node_distributor, num_ssds, page_size, num_elems, ssd_read_offset, cache_size,  # MB
                  batch_size, fan_out, dim, MPI_comm_manager, device, cache_backend="nvshmem", sim_buf=None,
-                 num_rows=None, profile=False):
+                 num_rows=None, profile=False, cold_partitioned=False):
         self.node_distributor = node_distributor
         self.device = device
         self.cache_backend = cache_backend
@@ -134,13 +134,17 @@ class COALA_GNN_Manager(object):
             self.NVshmem_tensor_manager = NVShmem_Tensor_Manager(self.max_sample_size, dim, G, self.device)
             self.COALA_GNN_Cache = SSD_GNN_NVSHMEM_Cache(self.SSD_Controllers, dm, MPI_comm_manager.global_rank, G, cache_size,
                                                          sim_ptr, num_rows=num_rows, profile=profile,
-                                                         max_batch=self.max_sample_size)
+                                                         max_batch=self.max_sample_size, rank=MPI_comm_manager.local_rank,
+                                                         cold_partitioned=cold_partitioned)
             self.exchange = AllToAllExchange(MPI_comm_manager.nccl_cache_gather, MPI_comm_manager.local_rank, G, dim, self.device)
             self.COALA_GNN_Cache.attach_exchange(self.exchange)
         elif self.cache_backend in ("isolated", "nccl"):      # :101-111
             self.COALA_GNN_Cache = Isolated_Cache(self.SSD_Controllers, dm, MPI_comm_manager.global_rank, G, cache_size,
                                                   sim_ptr, num_rows=num_rows, profile=profile,
-                                                  max_batch=self.max_sample_size)
+                                                  max_batch=self.max_sample_size, rank=MPI_comm_manager.local_rank,
+                                                  cold_partitioned=cold_partitioned and self.cache_backend == "nccl")
+            if cold_partitioned and self.cache_backend == "isolated":
+                raise ValueError("an isolated cache reads every row: it needs the whole cold table, not an owner's shard")
             if self.cache_backend == "nccl":
                 self.exchange = AllToAllExchange(MPI_comm_manager.nccl_cache_gather, MPI_comm_manager.local_rank, G, dim, self.device)
         else:

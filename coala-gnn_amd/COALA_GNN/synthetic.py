@@ -73,6 +73,17 @@ def fill_table(cpu_tensor, seed, device="cuda", chunk_rows=1 << 18, row0=0):
         torch.cuda.synchronize()
 
 
+def fill_table_partition(cpu_tensor, seed, rank, world, device="cuda", chunk_rows=1 << 18):
+    """Fill an owner's shard of the table: local row k holds node id k*world + rank (COALA_FLAG_COLD_PARTITIONED)."""
+    rows, dim = cpu_tensor.shape
+    for lo in range(0, rows, chunk_rows):
+        hi = min(rows, lo + chunk_rows)
+        ids = torch.arange(lo, hi, dtype=torch.int64, device=device) * world + rank
+        cpu_tensor[lo:hi].copy_(feature_rows_torch(ids, dim, seed))
+    if str(device).startswith("cuda"):
+        torch.cuda.synchronize()
+
+
 def alloc_pinned_table(num_rows, dim, seed, device=0):
     t = PinnedFeatureTable(num_rows, dim, device)
     fill_table(t.cpu_tensor, seed, device=f"cuda:{device}")

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("COALA_HIP_LIB", os.path.join(os.path.dirname(_HERE), "lib", "libcoala_hip.so"))
 
 OK, EINVAL, EHIP, ENOMEM, EIO, EFORMAT, ERANGE = 0, -1, -2, -3, -4, -5, -6
-FLAG_SYNC, FLAG_DISTRIBUTED, FLAG_PROFILE = 1, 2, 4
+FLAG_SYNC, FLAG_DISTRIBUTED, FLAG_PROFILE, FLAG_COLD_PARTITIONED = 1, 2, 4, 8
 WAYS = 32
 
 

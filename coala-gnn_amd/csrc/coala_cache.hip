@@ -52,6 +52,7 @@ struct CacheDev {
     int32_t gshift;        // log2(n_gpus) if power of two else -1
     int32_t sshift;        // log2(num_sets) if power of two else -1
     uint32_t distributed;
+    uint32_t cold_partitioned; // cold row of id = id / n_gpus
     // per-batch scratch, indexed by the row's POSITION in the batch (no compaction, no list counter)
     uint8_t* row_state;    // [cap] 0 hit (or idle), 1 miss, 2 rejected id; K1 sets non-zero values, K2 clears them again
     uint64_t* set_head;    // [sets] : (gen << 32) | (position + 1) of the most recently pushed miss of this set
@@ -70,6 +71,12 @@ __device__ __forceinline__ uint64_t set_of(const CacheDev& c, uint64_t id) {
     if (c.sshift >= 0) return k & (c.num_sets - 1);
     if ((k >> 32) == 0 && (c.num_sets >> 32) == 0) return (uint32_t)k % (uint32_t)c.num_sets;
     return k % c.num_sets;
+}
+
+__device__ __forceinline__ uint64_t cold_row_of(const CacheDev& c, uint64_t id) {
+    if (!c.cold_partitioned) return id;
+    if (c.gshift >= 0) return id >> c.gshift;
+    return id / c.n_gpus;
 }
 
 __device__ __forceinline__ uint64_t readlane64(uint64_t v, int src_lane) {
@@ -328,7 +335,7 @@ __global__ __launch_bounds__(256) void miss_fill_kernel(CacheDev c, const int64_
         }
 #pragma unroll
         for (int p = 0; p < G::PASSES; ++p) {
-            const V* src = reinterpret_cast<const V*>(c.cold + id[p] * (uint64_t)c.dim); // cold stride = dim
+            const V* src = reinterpret_cast<const V*>(c.cold + cold_row_of(c, id[p]) * (uint64_t)c.dim); // cold stride = dim
 #pragma unroll
             for (int v = 0; v < G::VPL; ++v) {
                 const uint32_t u = v * G::LPR + l_in;
@@ -673,6 +680,7 @@ int coala_cache_create(const coala_cache_config_t* cfg, coala_cache_t** out) {
     d.gshift = ilog2_exact((uint64_t)cfg->n_gpus);
     d.sshift = ilog2_exact(sets);
     d.distributed = (cfg->flags & COALA_FLAG_DISTRIBUTED) ? 1u : 0u;
+    d.cold_partitioned = (cfg->flags & COALA_FLAG_COLD_PARTITIONED) ? 1u : 0u;
     d.cold = cfg->cold_table;
     int rc = COALA_OK;
     auto alloc = [&](void** p, uint64_t bytes) -> int {

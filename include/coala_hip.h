@@ -34,6 +34,10 @@ extern "C" {
 #define COALA_FLAG_SYNC 1u        /* synchronise the stream before returning (reference semantics)            */
 #define COALA_FLAG_DISTRIBUTED 2u /* set = (id / n_gpus) % sets   (nvshmem_cache.h:191-196,347) instead of id % sets */
 #define COALA_FLAG_PROFILE 4u     /* record hipEvents around the probe+gather kernel (see coala_cache_profile) */
+#define COALA_FLAG_COLD_PARTITIONED 8u /* cold_table holds only this owner's rows: row k = node id k*n_gpus + rank, i.e. the
+                                          cold row of id is id / n_gpus.  An owner of the partitioned cache never reads any
+                                          other row, so each GPU pins 1/n_gpus of the table next to its own PCIe link instead
+                                          of all GPUs mapping one shared copy (shared_UVA.cuh:42-100).                        */
 
 const char* coala_last_error(void);
 /* ABI version of this header; bumped on any signature change. */

@@ -44,15 +44,22 @@ def _loopback_step(torch, caches, idx_list, dim):
     return outs
 
 
-@pytest.mark.parametrize("G,dim,cache_mb", [(2, 1024, 1), (4, 128, 1), (3, 100, 1), (8, 1024, 2)])
-def test_partitioned_cache_matches_oracle(hiplib, oracle, G, dim, cache_mb):
+@pytest.mark.parametrize("G,dim,cache_mb,cold_part", [(2, 1024, 1, False), (4, 128, 1, False), (3, 100, 1, True), (8, 1024, 2, True),
+                                                      (4, 256, 1, True)])
+def test_partitioned_cache_matches_oracle(hiplib, oracle, G, dim, cache_mb, cold_part):
     import torch
     P = hiplib
     num_rows = 12000
     feat = oracle.make_features(num_rows, dim, seed=4)
-    table = PinnedTable(P, feat)
     ctrl = P.SSD_GNN_SSD_Controllers(1, 4096, 1024, 0, 0, dim, True)
-    caches = [P.SSD_GNN_NVSHMEM_Cache(ctrl, None, r, G, cache_mb, table.device_ptr, num_rows=num_rows) for r in range(G)]
+    if cold_part:  # COALA_FLAG_COLD_PARTITIONED: owner r pins only rows r, r+G, r+2G, ...
+        shards = [PinnedTable(P, np.ascontiguousarray(feat[r::G])) for r in range(G)]
+        caches = [P.SSD_GNN_NVSHMEM_Cache(ctrl, None, r, G, cache_mb, shards[r].device_ptr, num_rows=num_rows, rank=r,
+                                          cold_partitioned=True) for r in range(G)]
+        table = shards[0]
+    else:
+        table = PinnedTable(P, feat)
+        caches = [P.SSD_GNN_NVSHMEM_Cache(ctrl, None, r, G, cache_mb, table.device_ptr, num_rows=num_rows, rank=r) for r in range(G)]
     orcs = [oracle.OracleCache(cache_mb, dim, feat, n_gpus=G, distributed=True) for _ in range(G)]
     rng = np.random.default_rng(G)
     for step in range(6):

@@ -49,6 +49,8 @@ def parse_args():
                     help="minibatch: sampler-produced ids (the metric). allhit/allmiss: kernel micro-benchmarks on unique uniform ids")
     ap.add_argument("--cpu-baseline-batches", type=int, default=120)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-allhit", action="store_true", help="skip the extra all-hit leg of the probe+gather kernel")
+    ap.add_argument("--allhit-launches", type=int, default=100)
     ap.add_argument("--seed", type=int, default=0)
     return ap.parse_args()
 
@@ -200,6 +202,33 @@ def main():
         "rank_avg_us": round(prof.rank_ms / max(prof.fill_launches, 1) * 1e3, 2),
     }
 
+    # ---------------------------------------------------------------- extra leg (N=1): the hit path alone
+    # BASELINE.md section 4 micro-benchmark: N = max rows per minibatch, unique uniform ids, cache pre-warmed with exactly
+    # those ids, so every row is a hit and the probe+gather kernel moves B_row = 2*dim*4 + 8 + 256 bytes per row.
+    roofline_allhit = None
+    if world == 1 and args.mode == "minibatch" and not args.no_allhit:
+        gen = torch.Generator(device=device).manual_seed(12345)
+        ids = torch.randperm(args.rows, generator=gen, device=device)[:max_rows]
+        for _ in range(3):
+            manager.fetch_feature((ids,))
+        torch.cuda.synchronize()
+        cache.stats(reset=True)
+        cache.profile(reset=True)
+        for _ in range(args.allhit_launches):
+            manager.fetch_feature((ids,))
+        torch.cuda.synchronize()
+        h2, m2, _ = cache.stats()
+        p2 = cache.profile()
+        l2 = max(p2.gather_launches, 1)
+        b2 = p2.gather_rows * (8 + 256) + p2.gather_hits * (2 * args.dim * 4)
+        us2 = p2.gather_ms / l2 * 1e3
+        ach2 = (b2 / l2) / (us2 * 1e-6) / 1e9 if us2 > 0 else 0.0
+        roofline_allhit = {"bound": "hbm", "kernel": "probe_gather_kernel", "achieved": round(ach2, 1), "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": round(ach2 / HBM_PEAK_GBS, 4), "avg_launch_us": round(us2, 2),
+                           "launches": int(p2.gather_launches), "rows_per_launch": round(p2.gather_rows / l2, 1),
+                           "hit_ratio": round(h2 / max(h2 + m2, 1), 4), "alg_bytes_per_launch": int(b2 / l2),
+                           "note": "untimed extra leg: every row a hit (pre-warmed unique uniform ids)"}
+
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_baseline = run_cpu_baseline(args, host_array, batches[args.warmup:], fanout)
@@ -220,6 +249,7 @@ def main():
                        "steps_per_epoch": steps_per_epoch,
                        "epoch_time_s_fetch_only_extrapolated": round(ms_per_step * steps_per_epoch / 1e3, 2)},
             "roofline": roofline,
+            "roofline_allhit": roofline_allhit,
             "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(line), flush=True)

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): rocprofv3 passes over the default bench command, results under gpurun_out/prof_*.
+#   kernel trace + stats  -> per-kernel durations (must agree with bench.py's hipEvent numbers)
+#   --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (MI355X_MICROARCH.md: 3 + 2 TCC slots, not in one pass)
+# tools/summarize_profiles.py then writes the tracked summaries into profiles/.
+set -e
+R=${GRAFT_REPO_ROOT:-$PWD}
+ARGS="${BENCH_ARGS:---no-cpu-baseline}"
+TAG="${TAG:-default}"
+export TMPDIR=/tmp
+cd /tmp
+mkdir -p $R/gpurun_out/prof_${TAG}_trace $R/gpurun_out/prof_${TAG}_fetch $R/gpurun_out/prof_${TAG}_write
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_trace -- python3 $R/bench.py $ARGS > $R/gpurun_out/prof_${TAG}_trace.log 2>&1
+echo "trace pass done"
+timeout -k 10 500 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_${TAG}_fetch -- python3 $R/bench.py $ARGS > $R/gpurun_out/prof_${TAG}_fetch.log 2>&1
+echo "fetch pass done"
+timeout -k 10 500 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_${TAG}_write -- python3 $R/bench.py $ARGS > $R/gpurun_out/prof_${TAG}_write.log 2>&1
+echo "write pass done"
+cd $R
+python3 tools/summarize_profiles.py $TAG

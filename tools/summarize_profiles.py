@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Condenses the rocprofv3 output of tools/profile_round.sh (gpurun_out/prof_<tag>_*) into small tracked files under
+profiles/: the per-kernel stats table, and the HBM traffic per launch of the probe+gather kernel from the PMC passes
+(FETCH_SIZE doubled, as /opt/skills/guides/MI355X_MICROARCH.md "HBM" prescribes for gfx950 wide coalesced reads)."""
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROUND = os.environ.get("ROUND", "r01")
+
+
+def find(tag, kind, suffix):
+    hits = glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{tag}_{kind}", "**", f"*{suffix}"), recursive=True)
+    return hits[0] if hits else None
+
+
+def bench_line(tag, kind):
+    p = os.path.join(ROOT, "gpurun_out", f"prof_{tag}_{kind}.log")
+    try:
+        for line in reversed(open(p).read().strip().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+    except Exception:
+        pass
+    return None
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "default"
+    out_dir = os.path.join(ROOT, "profiles")
+    os.makedirs(out_dir, exist_ok=True)
+    summary = {"round": ROUND, "tag": tag}
+    stats = find(tag, "trace", "kernel_stats.csv")
+    if stats:
+        rows = list(csv.DictReader(open(stats)))
+        keep = [r for r in rows if "coala" in r["Name"].lower() or "anonymous namespace" in r["Name"]]
+        with open(os.path.join(out_dir, f"{ROUND}_{tag}_kernel_stats.csv"), "w", newline="") as f:
+            w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+            w.writeheader()
+            for r in keep + [r for r in rows if r not in keep][:6]:
+                r = dict(r)
+                r["Name"] = r["Name"][:160]
+                w.writerow(r)
+    trace = find(tag, "trace", "kernel_trace.csv")
+    line = bench_line(tag, "trace")
+    steps = line["steps"] if line else 200
+    if trace:
+        rows = [r for r in csv.DictReader(open(trace)) if "probe_gather_kernel" in r["Kernel_Name"]]
+        rows = rows[-steps:]
+        durs = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
+        summary["probe_gather_avg_us_rocprof_timed_region"] = round(sum(durs) / max(len(durs), 1) / 1e3, 2)
+        summary["probe_gather_launches_timed_region"] = len(durs)
+        r0 = rows[-1] if rows else {}
+        summary["probe_gather_vgpr"] = r0.get("VGPR_Count") or r0.get("Arch_VGPR_Count")
+        summary["probe_gather_grid_block"] = [r0.get("Grid_Size_X") or r0.get("Grid_Size"), r0.get("Workgroup_Size_X") or r0.get("Workgroup_Size")]
+    if line:
+        summary["bench_roofline_from_hipEvents"] = line.get("roofline")
+        summary["bench_value"] = line.get("value")
+        summary["bench_ms_per_step"] = line.get("ms_per_step")
+        summary["bench_config"] = line.get("config")
+    pmc = {}
+    for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+        f = find(tag, kind, "counter_collection.csv")
+        if not f:
+            continue
+        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
+                if "probe_gather_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter]
+        vals = vals[-steps:]
+        if vals:
+            pmc[counter] = sum(vals) / len(vals)
+    if pmc:
+        # counters are in KiB; FETCH_SIZE reads exactly half of a wide coalesced stream on gfx950 -> doubled
+        fetch = pmc.get("FETCH_SIZE", 0.0) * 1024.0 * 2.0
+        write = pmc.get("WRITE_SIZE", 0.0) * 1024.0
+        summary["pmc"] = {"FETCH_SIZE_KiB_per_launch_raw": pmc.get("FETCH_SIZE"), "WRITE_SIZE_KiB_per_launch_raw": pmc.get("WRITE_SIZE"),
+                          "fetch_bytes_per_launch_corrected_x2": fetch, "write_bytes_per_launch": write,
+                          "hbm_bytes_per_launch": fetch + write,
+                          "note": "last <steps> dispatches of probe_gather_kernel; FETCH_SIZE x2 (gfx950: 128-B requests tallied at 64 B)"}
+        if tag == "default":
+            with open(os.path.join(out_dir, "pmc_probe_gather.json"), "w") as f:
+                json.dump({"hbm_bytes_per_launch": int(fetch + write), "source": f"profiles/{ROUND}_{tag}_summary.json"}, f)
+    with open(os.path.join(out_dir, f"{ROUND}_{tag}_summary.json"), "w") as f:
+        json.dump(summary, f, indent=1)
+    print(json.dumps(summary, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,83 @@
+"""End-to-end on one MI355X: shared pinned region across two processes, and the COALA_GNN_DataLoader iterator feeding a
+tiny GraphSAGE step (the consumer contract of examples/sbatch_ssd_gnn_train.py:129-145)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from _util import ColorFiles
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_shared_uva_two_processes_one_gpu():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_shm_worker.py")], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    for r, p in enumerate(procs):
+        out, _ = p.communicate(timeout=300)
+        assert p.returncode == 0 and f"rank {r} ok" in out, out[-3000:]
+
+
+@pytest.mark.parametrize("backend,method", [("isolated", "node_color"), ("nvshmem", "baseline")])
+def test_dataloader_epoch_and_sage_step(hiplib, oracle, tmp_path, backend, method):
+    import torch
+    from COALA_GNN import COALA_GNN_DataLoader, MPI_Comm_Manager, Node_Distributor, SSD_INFO
+    from COALA_GNN.sampler import NeighborSampler
+    from COALA_GNN.synthetic import alloc_pinned_table, block_colors, feature_rows_torch, powerlaw_csc
+    torch.manual_seed(0)
+    n_nodes, dim, batch, fan = 20000, 128, 64, [5, 5]
+    table = alloc_pinned_table(n_nodes, dim, seed=3, device=0)
+    indptr, indices = powerlaw_csc(n_nodes, 8.0, seed=1, device="cuda")
+    labels = (torch.arange(n_nodes, device="cuda") * 7) % 5
+    color, tk, sc, ncol = block_colors(n_nodes, nodes_per_color=512)
+    files = ColorFiles(tmp_path, color, tk, sc)
+    comm = MPI_Comm_Manager(0)
+    comm.initialize_nested_process_group(backend)
+    train_ids = torch.randperm(int(0.6 * n_nodes), generator=torch.Generator().manual_seed(0))[:64 * 12]
+    nd = Node_Distributor(comm, train_ids, batch, files.color_file, files.topk_file, files.score_file, parsing_method=method)
+    sampler = NeighborSampler(fan, seed=5)
+    g = sampler.make_graph(indptr, indices, ndata={"labels": labels})
+    loader = COALA_GNN_DataLoader(SSD_INFO(1, dim * 4, 1024, 0), nd, g, sampler, batch, dim, fan, 4, "cuda:0", refresh_counter=3,
+                                  cache_backend=backend, sim_buf=table, num_rows=n_nodes)
+    assert loader.total_count == 12 - 1  # COALA_GNN_DataLoader.py:141
+    w1 = torch.nn.Linear(2 * dim, 32).cuda()
+    w2 = torch.nn.Linear(64, 5).cuda()
+    opt = torch.optim.Adam(list(w1.parameters()) + list(w2.parameters()), lr=1e-2)
+    for epoch in range(2):
+        steps, seen = 0, []
+        for input_nodes, seeds, blocks, feat in loader:
+            assert feat.shape == (input_nodes.numel(), dim) and feat.is_cuda
+            assert torch.equal(feat, feature_rows_torch(input_nodes, dim, 3))      # the cache is a transparent gather
+            assert torch.equal(blocks[0].src_nodes, input_nodes) and blocks[-1].num_dst == batch
+            batch_labels = blocks[-1].dstdata["labels"]
+            blocks = [b.int().to("cuda:0") for b in blocks]
+            h = feat
+            h = torch.relu(w1(torch.cat([h[: blocks[0].num_dst], blocks[0].mean_aggregate(h)], 1)))   # SAGE-mean layer 1
+            h = w2(torch.cat([h[: blocks[1].num_dst], blocks[1].mean_aggregate(h)], 1))               # layer 2
+            loss = torch.nn.functional.cross_entropy(h, batch_labels.view(-1))
+            opt.zero_grad(); loss.backward(); opt.step()
+            assert torch.isfinite(loss)
+            seen.append(seeds.cpu())
+            steps += 1
+        assert steps == 11
+        assert torch.equal(torch.cat(seen), train_ids[: 11 * batch])  # one domain: contiguous striping in order
+    loader.print_stats()
+    hit, miss, bad = loader.COALA_GNN_Manager.COALA_GNN_Cache.stats()
+    assert bad == 0
+    cc = np.zeros(ncol + 1, dtype=np.int32)
+    loader.COALA_GNN_Manager.get_cache_data(cc.ctypes.data, ncol + 1)
+    geo = loader.COALA_GNN_Manager.COALA_GNN_Cache.geometry()
+    keys, _, _ = loader.COALA_GNN_Manager.COALA_GNN_Cache.dump()
+    assert cc[1:].sum() == int((keys != np.uint64(0xFFFFFFFFFFFFFFFF)).sum())  # colour occupancy == live lines
+    assert cc[0] == -cc[1:].sum()                                                 # colour 0 absorbed the first-touch decrements
+    del loader
+    table.close()

@@ -22,7 +22,7 @@ _lib = _capi.load()
 
 __all__ = [
     "SharedUVAManager", "SSD_GNN_SSD_Controllers", "SSD_GNN_NVSHMEM_Cache", "Isolated_Cache", "Node_distributor_pybind",
-    "NVSHMEM_Manager", "current_stream", "set_stream_provider",
+    "NVSHMEM_Manager", "Graph_Coloring", "current_stream", "set_stream_provider",
 ]
 
 
@@ -360,3 +360,56 @@ class NVSHMEM_Manager:
 
     def finalize(self):
         self._bufs.clear()
+
+
+# ------------------------------------------------------------------------------------------------------------ colouring
+class Graph_Coloring:
+    """graph_coloring.h:15-68 / COALA_GNN_Pybind.cu:65-77.  Graph_Coloring(num_nodes); buffers are host int64 / float64
+    tensors passed by address, exactly as examples/color_info_gen/generate_color_data.py:20-54 does."""
+
+    def __init__(self, num_nodes, topk=10, seed=1):
+        self._h = C.c_void_p()
+        check(_lib.coala_coloring_create(int(num_nodes), C.byref(self._h)))
+        self.topk = int(topk)
+        self.seed = int(seed)  # 1 == the reference's unseeded glibc rand() stream
+
+    def set_adj_csc(self, i_indp, i_indices):
+        check(_lib.coala_coloring_set_adj_csc(self._h, int(i_indp), int(i_indices)))
+
+    def set_color_buffer(self, i_ptr):
+        check(_lib.coala_coloring_set_color_buffer(self._h, int(i_ptr)))
+
+    def set_topk_color_buffer(self, i_ptr):
+        check(_lib.coala_coloring_set_topk_buffers(self._h, int(i_ptr), None, self.topk))
+
+    def set_topk_affinity_buffer(self, i_ptr):
+        check(_lib.coala_coloring_set_topk_buffers(self._h, None, int(i_ptr), self.topk))
+
+    def cpu_color_graph(self):
+        check(_lib.coala_coloring_color_all(self._h, self.seed))
+
+    def cpu_color_graph_optimized(self, i_train_node_ptr, num_training_nodes):
+        check(_lib.coala_coloring_color_optimized(self._h, int(i_train_node_ptr), int(num_training_nodes), self.seed))
+
+    def cpu_count_nearest_color(self):
+        check(_lib.coala_coloring_nearest(self._h))
+
+    def cpu_count_nearest_color_less_memory(self):
+        check(_lib.coala_coloring_topk(self._h, 0))
+
+    def cpu_calculate_color_affinity(self):
+        check(_lib.coala_coloring_topk(self._h, 1))
+
+    def get_num_color(self):
+        return int(_lib.coala_coloring_num_color(self._h))
+
+    def get_num_color_node(self):
+        return int(_lib.coala_coloring_num_color_node(self._h))
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.coala_coloring_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass

@@ -50,6 +50,17 @@ SYMBOLS = {
     "coala_cache_stats": (_I, [_VP, C.POINTER(_U64), C.POINTER(_U64), C.POINTER(_U64), _I, _VP]),
     "coala_cache_dump": (_I, [_VP, _VP, _VP, _VP, _VP]),
     "coala_cache_profile": (_I, [_VP, C.POINTER(CacheProfile), _I]),
+    "coala_coloring_create": (_I, [_U64, C.POINTER(_VP)]),
+    "coala_coloring_destroy": (_I, [_VP]),
+    "coala_coloring_set_adj_csc": (_I, [_VP, _VP, _VP]),
+    "coala_coloring_set_color_buffer": (_I, [_VP, _VP]),
+    "coala_coloring_set_topk_buffers": (_I, [_VP, _VP, _VP, _I]),
+    "coala_coloring_color_optimized": (_I, [_VP, _VP, _U64, C.c_uint]),
+    "coala_coloring_color_all": (_I, [_VP, C.c_uint]),
+    "coala_coloring_num_color": (_U64, [_VP]),
+    "coala_coloring_num_color_node": (_U64, [_VP]),
+    "coala_coloring_topk": (_I, [_VP, _I]),
+    "coala_coloring_nearest": (_I, [_VP]),
     "coala_sampler_create": (_I, [_I, _VP, _VP, _I64, _I64, C.POINTER(_VP)]),
     "coala_sampler_destroy": (_I, [_VP]),
     "coala_sampler_sample": (_I, [_VP, _VP, _I64, C.POINTER(C.c_int32), _I, _U64, _U64, C.POINTER(_VP), C.POINTER(_VP),

@@ -5,7 +5,7 @@ import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("coala_cache.hip", "coala_sampler.hip", "coala_host.cpp")]
+SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("coala_cache.hip", "coala_sampler.hip", "coala_host.cpp", "coala_coloring.cpp")]
 HEADERS = [os.path.join(_ROOT, "include", "coala_hip.h"), os.path.join(_HERE, "csrc", "coala_internal.h")]
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libcoala_hip.so")

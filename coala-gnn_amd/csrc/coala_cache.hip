@@ -93,13 +93,13 @@ template <> struct VecT<4> { using type = vfloat4; };
 template <> struct VecT<1> { using type = float; };
 
 // Geometry of the row movers.  VEC = floats per lane access (4 -> 16-B accesses; 1 -> fallback for dim % 4 != 0).
-template <int CD, int VEC>
+template <int CD, int VEC, int NP = 4>
 struct Geo {
     static constexpr int UNITS = CD / VEC;                    // accesses per full line
     static constexpr int LPR = UNITS >= 64 ? 64 : UNITS;      // lanes per row
     static constexpr int RPP = 64 / LPR;                      // rows per pass (2 for 512-B lines with 16-B accesses)
     static constexpr int VPL = UNITS / LPR;                   // accesses per lane per row
-    static constexpr int PASSES = (VPL >= 16) ? 1 : 4;        // rows(-pairs) in flight per wave
+    static constexpr int PASSES = (VPL >= 16) ? 1 : NP;       // rows(-pairs) in flight per wave
     static constexpr int R = RPP * PASSES;                    // rows per chunk
 };
 
@@ -117,10 +117,10 @@ constexpr int kK1Waves = 2; // waves per block (measured: 2048 x 128 threads bea
 template <typename V> __device__ __forceinline__ V nt_load(const V* p) { return __builtin_nontemporal_load(p); }
 template <typename V> __device__ __forceinline__ void nt_store(V v, V* p) { __builtin_nontemporal_store(v, p); }
 
-template <int CD, int VEC>
+template <int CD, int VEC, int NP = 4>
 __global__ __launch_bounds__(64 * kK1Waves) void probe_gather_kernel(CacheDev c, const int64_t* __restrict__ idx,
                                                                     float* __restrict__ out, int64_t n, uint32_t gen) {
-    using G = Geo<CD, VEC>;
+    using G = Geo<CD, VEC, NP>;
     using V = typename VecT<VEC>::type;
     constexpr int R = G::R;
     constexpr int TSTEPS = (R + 3) / 4; // tag loads: four sets per wave-wide 16-B load (16 lanes x 2 keys per set)
@@ -266,10 +266,10 @@ __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src) {
     return ((uint64_t)hi << 32) | lo;
 }
 
-template <int CD, int VEC>
+template <int CD, int VEC, int NP = 4>
 __global__ __launch_bounds__(256) void miss_fill_kernel(CacheDev c, const int64_t* __restrict__ idx, float* __restrict__ out,
                                                         int64_t n) {
-    using G = Geo<CD, VEC>;
+    using G = Geo<CD, VEC, NP>;
     using V = typename VecT<VEC>::type;
     constexpr int R = G::R;
     const int lane = threadIdx.x & 63;
@@ -372,10 +372,10 @@ __global__ __launch_bounds__(256) void miss_fill_kernel(CacheDev c, const int64_
 
 // ---------------------------------------------------------------------------------------------------------- scatter
 // out[map[r], :] = src[r, :]   (cache_kernel.cu:113-137)
-template <int CD, int VEC>
+template <int CD, int VEC, int NP = 4>
 __global__ __launch_bounds__(256) void scatter_rows_kernel(float* __restrict__ out, const float* __restrict__ src,
                                                            const int64_t* __restrict__ map, int64_t n, uint32_t dim) {
-    using G = Geo<CD, VEC>;
+    using G = Geo<CD, VEC, NP>;
     using V = typename VecT<VEC>::type;
     constexpr int R = G::R;
     const int lane = threadIdx.x & 63;
@@ -535,6 +535,8 @@ struct coala_cache {
     std::vector<hipEvent_t> ev_pool;
     coala_cache_profile_t prof{};
     uint64_t table_bytes = 0;
+    int k1_passes = 4;                    // rows(-pairs) in flight per wave in K1 (tunable: COALA_K1_PASSES = 2 | 4)
+    int k1_grid_cap = 256 * 8;            // K1 blocks (tunable: COALA_K1_GRID)
     uint64_t rows_total = 0;              // rows submitted since the last stats reset (hits = rows - misses - rejected)
     uint64_t cum_hit = 0, cum_miss = 0;   // totals folded in whenever coala_cache_stats resets the device counters
     uint64_t prof_hit0 = 0, prof_miss0 = 0; // totals at the last profile reset
@@ -724,6 +726,8 @@ int coala_cache_create(const coala_cache_config_t* cfg, coala_cache_t** out) {
             d.node_color = h->node_color_dev;
         }
         h->gen = 0;
+        if (const char* e = getenv("COALA_K1_PASSES")) h->k1_passes = atoi(e) == 2 ? 2 : 4;
+        if (const char* e = getenv("COALA_K1_GRID")) { int g = atoi(e); if (g >= 1 && g <= 65535) h->k1_grid_cap = g; }
         if (cfg->max_batch) rc = ensure_scratch(h, cfg->max_batch, nullptr);
     } while (0);
     if (rc == COALA_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(COALA_EHIP, "device sync failed after create");
@@ -783,11 +787,18 @@ static int read_feature_impl(coala_cache_t* h, float* out, const int64_t* idx, i
         constexpr int VEC = geo_vec(geo);
         using G = Geo<CD, VEC>;
         const int64_t chunks = (n + G::R - 1) / G::R;
-        // K1: 2-wave blocks, 16 waves per CU resident (4 per SIMD at ~118 VGPRs); grid-stride over the chunks
+        // K1: 2-wave blocks, every wave resident; grid-stride over the chunks
         {
             ProfScope ps(h, s, 0, (uint64_t)n);
-            hipLaunchKernelGGL((probe_gather_kernel<CD, VEC>), dim3(grid_for(chunks, kK1Waves, 256 * 8)), dim3(64 * kK1Waves), 0, s, d, idx,
-                               out, n, gen);
+            if (h->k1_passes == 2) {
+                using G2 = Geo<CD, VEC, 2>;
+                const int64_t chunks2 = (n + G2::R - 1) / G2::R;
+                hipLaunchKernelGGL((probe_gather_kernel<CD, VEC, 2>), dim3(grid_for(chunks2, kK1Waves, h->k1_grid_cap)), dim3(64 * kK1Waves), 0,
+                                   s, d, idx, out, n, gen);
+            } else {
+                hipLaunchKernelGGL((probe_gather_kernel<CD, VEC, 4>), dim3(grid_for(chunks, kK1Waves, h->k1_grid_cap)), dim3(64 * kK1Waves), 0,
+                                   s, d, idx, out, n, gen);
+            }
         }
         {
             ProfScope ps(h, s, 2, 0);

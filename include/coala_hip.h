@@ -143,6 +143,28 @@ typedef struct coala_cache_profile {
 int coala_cache_profile(coala_cache_t* h, coala_cache_profile_t* out, int reset);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Offline graph colouring + colour-affinity tables (host only).  Replaces Graph_Coloring
+ * (COALA_GNN_Modules/graph_coloring.h:15-68, graph_coloring.cpp) driven by examples/color_info_gen/generate_color_data.py.
+ * All buffers are HOST pointers owned by the caller, int64 (the reference aliases int64 torch tensors as uint64).
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct coala_coloring coala_coloring_t;
+int coala_coloring_create(uint64_t num_nodes, coala_coloring_t** out);                                  /* Graph_Coloring(u64) */
+int coala_coloring_destroy(coala_coloring_t* g);
+int coala_coloring_set_adj_csc(coala_coloring_t* g, const int64_t* indptr, const int64_t* indices);     /* set_adj_csc */
+int coala_coloring_set_color_buffer(coala_coloring_t* g, int64_t* color);                               /* set_color_buffer (zeroed [N]) */
+/* set_topk_color_buffer / set_topk_affinity_buffer: [num_colors*topk]; either pointer may be NULL to keep the current one */
+int coala_coloring_set_topk_buffers(coala_coloring_t* g, int64_t* topk_color, double* topk_affinity, int topk);
+/* cpu_color_graph_optimized(train_ptr, n): seeds sampled from the training nodes with glibc rand(); seed 1 reproduces the
+ * reference (which never calls srand) */
+int coala_coloring_color_optimized(coala_coloring_t* g, const int64_t* train, uint64_t n_train, unsigned seed);
+int coala_coloring_color_all(coala_coloring_t* g, unsigned seed);                                       /* cpu_color_graph */
+uint64_t coala_coloring_num_color(const coala_coloring_t* g);                                           /* get_num_color */
+uint64_t coala_coloring_num_color_node(const coala_coloring_t* g);                                      /* get_num_color_node */
+/* with_affinity=1: cpu_calculate_color_affinity; 0: cpu_count_nearest_color_less_memory */
+int coala_coloring_topk(coala_coloring_t* g, int with_affinity);
+int coala_coloring_nearest(coala_coloring_t* g);                                                        /* cpu_count_nearest_color */
+
+/* ------------------------------------------------------------------------------------------------------------
  * Neighbour sampler + block compaction over a CSC graph resident in device-visible memory (HBM, or pinned host).
  * Replaces the DGL call on the hot path: graph_sampler.sample(g, seeds) with
  * dgl.dataloading.MultiLayerNeighborSampler(fanouts) (COALA-GNN-Setup/COALA_GNN/COALA_GNN_DataLoader.py:162,

@@ -51,6 +51,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-allhit", action="store_true", help="skip the extra all-hit leg of the probe+gather kernel")
     ap.add_argument("--allhit-launches", type=int, default=100)
+    ap.add_argument("--epoch-steps", type=int, default=150, help="steps of the end-to-end leg (loader + GraphSAGE step); 0 = skip")
     ap.add_argument("--seed", type=int, default=0)
     return ap.parse_args()
 
@@ -229,6 +230,11 @@ def main():
                            "hit_ratio": round(h2 / max(h2 + m2, 1), 4), "alg_bytes_per_launch": int(b2 / l2),
                            "note": "untimed extra leg: every row a hit (pre-warmed unique uniform ids)"}
 
+    # ---------------------------------------------------------------- extra leg (N=1): end-to-end training steps
+    epoch = None
+    if world == 1 and args.mode == "minibatch" and args.epoch_steps > 0:
+        epoch = run_epoch_leg(args, comm, graph, sampler, table, device, fanout, steps_per_epoch)
+
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_baseline = run_cpu_baseline(args, host_array, batches[args.warmup:], fanout)
@@ -250,6 +256,7 @@ def main():
                        "epoch_time_s_fetch_only_extrapolated": round(ms_per_step * steps_per_epoch / 1e3, 2)},
             "roofline": roofline,
             "roofline_allhit": roofline_allhit,
+            "epoch": epoch,
             "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(line), flush=True)
@@ -258,6 +265,43 @@ def main():
     del manager
     if world > 1:
         comm.destroy_process_group()
+
+
+def run_epoch_leg(args, comm, graph, sampler, table, device, fanout, steps_per_epoch):
+    """distribute -> sample -> fetch -> GraphSAGE fwd/bwd/Adam per step, through COALA_GNN_DataLoader, serial (the
+    reference's __next__) and with the prefetching producer; epoch time extrapolated to steps_per_epoch."""
+    import tempfile
+    from COALA_GNN import COALA_GNN_DataLoader, Node_Distributor, SSD_INFO
+    from COALA_GNN.harness import SageMean, train_steps
+    from COALA_GNN.synthetic import block_colors
+    out = {"model": "GraphSAGE 2-layer mean, hidden 128, 19 classes, Adam (torch; out of scope, harness only)",
+           "per_step": "distribute + sample + fetch_feature + forward/backward/optimizer", "steps_per_epoch": steps_per_epoch}
+    with tempfile.TemporaryDirectory() as tmp:
+        color, tk, sc, _ = block_colors(args.rows, nodes_per_color=4096)
+        files = [os.path.join(tmp, f) for f in ("color.npy", "topk.npy", "score.npy")]
+        np.save(files[0], color); np.save(files[1], tk); np.save(files[2], sc)
+        del color
+        n_train = int(0.6 * args.rows)
+        need = (args.epoch_steps * 2 + 260) * args.batch
+        train_ids = torch.randperm(n_train, generator=torch.Generator().manual_seed(1))[: min(n_train, need)]
+        graph.ndata["labels"] = (torch.arange(args.rows, device=device) * 7) % 19
+        for name, prefetch in (("serial", 0), ("prefetch", 2)):
+            nd = Node_Distributor(comm, train_ids, args.batch, *files, parsing_method="baseline")
+            loader = COALA_GNN_DataLoader(SSD_INFO(1, args.dim * 4, 1024, 0), nd, graph, sampler, args.batch, args.dim, fanout,
+                                          args.cache_mb, device, cache_backend="isolated", sim_buf=table, num_rows=args.rows,
+                                          prefetch=prefetch)
+            model = SageMean(args.dim, 128, 19).to(device)
+            opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+            train_steps(loader, model, opt, 100, device)                       # warm the cache and the allocator
+            steps, secs, nodes = train_steps(loader, model, opt, args.epoch_steps, device)
+            ms = secs / max(steps, 1) * 1e3
+            out[name] = {"steps": steps, "ms_per_step": round(ms, 3), "epoch_time_s_extrapolated": round(ms * steps_per_epoch / 1e3, 2),
+                         "sampled_nodes_per_step": round(nodes / max(steps, 1), 1)}
+            log(f"[{name}] Epoch Time: {ms * steps_per_epoch / 1e3:.2f} (extrapolated from {steps} steps, {ms:.3f} ms/step)")
+            for _ in loader:  # drain the epoch so that the producer thread and the distributor threads end cleanly
+                pass
+            del loader, nd
+    return out
 
 
 def _pmc_traffic():

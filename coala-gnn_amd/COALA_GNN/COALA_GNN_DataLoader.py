@@ -4,6 +4,7 @@ Mirror of COALA-GNN-Setup/COALA_GNN/COALA_GNN_DataLoader.py (reference): COALA_G
 SSD_INFO :80-90, COALA_GNN_DataLoader :92-177 -- same names, arguments, cadence and double buffering.
 `graph_sampler` only needs .sample(graph, seed_ids) returning a tuple whose first element is the int64 input-node
 tensor (a DGL sampler object works when dgl imports; COALA_GNN.sampler.NeighborSampler is the native one)."""
+import queue
 import threading
 
 import torch
@@ -11,6 +12,21 @@ import torch
 from .COALA_GNN_Manager import COALA_GNN_Manager
 
 __all__ = ["COALA_GNN_Node_Distribution_Scheduler", "SSD_INFO", "COALA_GNN_DataLoader"]
+
+
+def _device_tensors(obj):
+    if isinstance(obj, torch.Tensor):
+        if obj.is_cuda:
+            yield obj
+    elif isinstance(obj, (list, tuple)):
+        for x in obj:
+            yield from _device_tensors(x)
+    elif isinstance(obj, dict):
+        for x in obj.values():
+            yield from _device_tensors(x)
+    elif hasattr(obj, "tensors"):
+        for x in obj.tensors():
+            yield from _device_tensors(x)
 
 
 class COALA_GNN_Node_Distribution_Scheduler(object):
@@ -79,8 +95,15 @@ class SSD_INFO(object):  # COALA_GNN_DataLoader.py:80-90
 
 class COALA_GNN_DataLoader(torch.utils.data.DataLoader):
     def __init__(self, SSD_info, node_distributor, graph, graph_sampler, batch_size, dim, fan_out, cache_size, device,
-                 refresh_counter=10, cache_backend="nvshmem", sim_buf=None, shuffle=False, num_rows=None, profile=False):
+                 refresh_counter=10, cache_backend="nvshmem", sim_buf=None, shuffle=False, num_rows=None, profile=False,
+                 prefetch=0, cold_partitioned=False):
         # like the reference, torch's DataLoader.__init__ is never called: this is a plain iterator
+        # prefetch = 0: the reference's strictly serial __next__ (:149-167).  prefetch = k > 0: a producer thread runs
+        # distribute -> sample -> fetch for the next k steps on its own HIP stream while the consumer trains (SURVEY f-2).
+        self.prefetch = int(prefetch)
+        self._producer = None
+        self._queue = None
+        self._side_stream = None
         self.refresh_counter = refresh_counter
         self.sampler = graph_sampler
         self.batch_size = batch_size
@@ -94,7 +117,8 @@ class COALA_GNN_DataLoader(torch.utils.data.DataLoader):
             node_distributor=node_distributor, page_size=SSD_info.page_size, num_ssds=SSD_info.num_ssds,
             num_elems=SSD_info.num_elems, ssd_read_offset=SSD_info.ssd_read_offset, cache_size=cache_size,
             batch_size=batch_size, fan_out=fan_out, dim=dim, MPI_comm_manager=node_distributor.comm_manager, device=device,
-            cache_backend=cache_backend, sim_buf=sim_buf, num_rows=num_rows, profile=profile)
+            cache_backend=cache_backend, sim_buf=sim_buf, num_rows=num_rows, profile=profile,
+            cold_partitioned=cold_partitioned)
         self.scheduler = COALA_GNN_Node_Distribution_Scheduler(node_distributor=self.node_distributor,
                                                                ssd_gnn_manager=self.COALA_GNN_Manager,
                                                                refresh_counter=self.refresh_counter)
@@ -111,12 +135,7 @@ class COALA_GNN_DataLoader(torch.utils.data.DataLoader):
     def __len__(self):
         return max(self.total_count, 0)
 
-    def __next__(self):  # COALA_GNN_DataLoader.py:149-167
-        if self.counter >= self.total_count:
-            self.scheduler.drain()  # the reference resets while a distributor thread may still run
-            self.node_distributor.reset()
-            self.counter = 0
-            raise StopIteration
+    def _produce_one(self):
         # last step of the epoch: do not launch a distributor thread past the end of the id list (the
         # reference's is_last test compares a step counter with the id count and never fires)
         is_last_iter = self.counter + 1 >= self.total_count
@@ -124,6 +143,56 @@ class COALA_GNN_DataLoader(torch.utils.data.DataLoader):
         batch = self.sampler.sample(self.g, distributed_index)
         self.counter += 1
         return self.COALA_GNN_Manager.fetch_feature(batch)
+
+    def _end_of_epoch(self):
+        self.scheduler.drain()  # the reference resets while a distributor thread may still run
+        self.node_distributor.reset()
+        self.counter = 0
+
+    def _producer_loop(self):
+        try:
+            torch.cuda.set_device(self.device)
+            with torch.cuda.stream(self._side_stream):
+                while self.counter < self.total_count:
+                    item = self._produce_one()
+                    ev = torch.cuda.Event()
+                    ev.record(self._side_stream)
+                    self._queue.put((item, ev))
+            self._queue.put(None)
+        except BaseException as e:  # surface producer failures in the consumer
+            self._queue.put(e)
+
+    def __next__(self):  # COALA_GNN_DataLoader.py:149-167
+        if self.prefetch <= 0:
+            if self.counter >= self.total_count:
+                self._end_of_epoch()
+                raise StopIteration
+            return self._produce_one()
+        if self._producer is None:
+            if self.total_count <= 0:
+                raise StopIteration
+            self._queue = queue.Queue(maxsize=self.prefetch)
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(device=self.device)
+            self._producer = threading.Thread(target=self._producer_loop, daemon=True)
+            self._producer.start()
+        got = self._queue.get()
+        if got is None or isinstance(got, BaseException):
+            self._producer.join()
+            self._producer = None
+            self._end_of_epoch()
+            if got is None:
+                raise StopIteration
+            raise got
+        item, ev = got
+        cur = torch.cuda.current_stream()
+        cur.wait_event(ev)  # the consumer's stream sees the finished rows
+        # Everything in the item was allocated on the producer's stream: tell the caching allocator that the consumer's
+        # stream uses it too, or the memory can be handed to the producer's next step while consumer kernels still read it
+        # (seen as garbage neighbour indices -> device-side index assert).
+        for t in _device_tensors(item):
+            t.record_stream(cur)
+        return item
 
     def print_stats(self):  # :170-174
         self.COALA_GNN_Manager.print_stats()
@@ -133,6 +202,8 @@ class COALA_GNN_DataLoader(torch.utils.data.DataLoader):
 
     def __del__(self):
         try:
+            if self._producer is not None:
+                self._producer.join(timeout=30)
             self.scheduler.drain()
             del self.COALA_GNN_Manager
         except Exception:

@@ -1,0 +1,45 @@
+"""Small consumer of the loader's 4-tuple, used by bench.py's epoch leg and the tests: a 2-layer GraphSAGE (mean) in plain
+torch on the native Block objects.  Stands where examples/models.py:DistSAGE + dgl.nn.SAGEConv stand in the reference's
+training script (examples/sbatch_ssd_gnn_train.py:98-145); the model itself is out of scope (dense compute downstream of
+the path), this is harness plumbing."""
+import time
+
+import torch
+
+__all__ = ["SageMean", "train_steps"]
+
+
+class SageMean(torch.nn.Module):
+    def __init__(self, in_dim, hidden, n_classes, n_layers=2):
+        super().__init__()
+        dims = [in_dim] + [hidden] * (n_layers - 1) + [n_classes]
+        self.lin_self = torch.nn.ModuleList(torch.nn.Linear(dims[i], dims[i + 1]) for i in range(n_layers))
+        self.lin_nbr = torch.nn.ModuleList(torch.nn.Linear(dims[i], dims[i + 1], bias=False) for i in range(n_layers))
+
+    def forward(self, blocks, h):
+        for i, b in enumerate(blocks):
+            h = self.lin_self[i](h[: b.num_dst]) + self.lin_nbr[i](b.mean_aggregate(h))
+            if i + 1 < len(blocks):
+                h = torch.relu(h)
+        return h
+
+
+def train_steps(loader, model, optimizer, max_steps, device):
+    """Runs up to max_steps iterations of the reference's training loop body; returns (steps, seconds, sampled_nodes)."""
+    loss_fn = torch.nn.CrossEntropyLoss()
+    steps = nodes = 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for input_nodes, seeds, blocks, feat in loader:
+        nodes += len(input_nodes)
+        labels = blocks[-1].dstdata["labels"].view(-1).to(device)
+        blocks = [b.int().to(device) for b in blocks]
+        loss = loss_fn(model(blocks, feat), labels)
+        optimizer.zero_grad()
+        loss.backward()
+        optimizer.step()
+        steps += 1
+        if steps >= max_steps:
+            break
+    torch.cuda.synchronize()
+    return steps, time.perf_counter() - t0, nodes

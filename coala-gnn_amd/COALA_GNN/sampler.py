@@ -59,6 +59,15 @@ class Block(object):
             for k, v in graph.ndata.items():  # blocks[-1].dstdata['labels'] (examples/sbatch_ssd_gnn_train.py:138)
                 self.dstdata[k] = v[self.dstdata["_ID"]] if v.device == src_nodes.device else v[self.dstdata["_ID"].cpu()]
 
+    def tensors(self):
+        """Every device tensor this block holds (for cross-stream lifetime bookkeeping by the prefetching loader)."""
+        yield self.src_nodes
+        yield self.nbr
+        for d in (self.srcdata, self.dstdata):
+            for v in d.values():
+                if isinstance(v, torch.Tensor):
+                    yield v
+
     def number_of_src_nodes(self):
         return self.num_src
 

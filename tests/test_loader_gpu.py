@@ -27,8 +27,9 @@ def test_shared_uva_two_processes_one_gpu():
         assert p.returncode == 0 and f"rank {r} ok" in out, out[-3000:]
 
 
-@pytest.mark.parametrize("backend,method", [("isolated", "node_color"), ("nvshmem", "baseline")])
-def test_dataloader_epoch_and_sage_step(hiplib, oracle, tmp_path, backend, method):
+@pytest.mark.parametrize("backend,method,prefetch", [("isolated", "node_color", 0), ("nvshmem", "baseline", 0), ("isolated", "baseline", 2),
+                                                     ("nccl", "node_color", 1)])
+def test_dataloader_epoch_and_sage_step(hiplib, oracle, tmp_path, backend, method, prefetch):
     import torch
     from COALA_GNN import COALA_GNN_DataLoader, MPI_Comm_Manager, Node_Distributor, SSD_INFO
     from COALA_GNN.sampler import NeighborSampler
@@ -47,7 +48,7 @@ def test_dataloader_epoch_and_sage_step(hiplib, oracle, tmp_path, backend, metho
     sampler = NeighborSampler(fan, seed=5)
     g = sampler.make_graph(indptr, indices, ndata={"labels": labels})
     loader = COALA_GNN_DataLoader(SSD_INFO(1, dim * 4, 1024, 0), nd, g, sampler, batch, dim, fan, 4, "cuda:0", refresh_counter=3,
-                                  cache_backend=backend, sim_buf=table, num_rows=n_nodes)
+                                  cache_backend=backend, sim_buf=table, num_rows=n_nodes, prefetch=prefetch)
     assert loader.total_count == 12 - 1  # COALA_GNN_DataLoader.py:141
     w1 = torch.nn.Linear(2 * dim, 32).cuda()
     w2 = torch.nn.Linear(64, 5).cuda()

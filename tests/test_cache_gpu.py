@@ -235,3 +235,72 @@ def test_full_size_config2_properties(hiplib, torch_cuda):
         assert (hit, miss, bad) == (*want_stats, 0)
     cache.close()
     table.close()
+
+
+def test_full_size_config2_counters_match_tag_only_oracle(hiplib, oracle, torch_cuda):
+    """BASELINE config 2 at full per-minibatch size (4 GiB cache = 32,768 sets, N = 36,864, dim 1024): hit / miss counters
+    and the whole tag table equal the oracle's (tag-only mode: no payload on the CPU side) over a sequence of minibatches
+    with a hot working set; rows are checked against the procedural table on the GPU."""
+    torch = torch_cuda
+    P = hiplib
+    from COALA_GNN.synthetic import alloc_pinned_table, feature_rows_torch
+    dim, num_rows, cache_mb, n = 1024, 3_000_000, 4096, 36864
+    table = alloc_pinned_table(num_rows, dim, seed=9, device=0)
+    ctrl = P.SSD_GNN_SSD_Controllers(1, 4096, 1024, 0, 0, dim, True)
+    cache = P.Isolated_Cache(ctrl, None, 0, 1, cache_mb, table.device_ptr, num_rows=num_rows)
+    orc = oracle.OracleCache(cache_mb, dim, np.zeros((1, dim), dtype=np.float32), tag_only=True)
+    rng = np.random.default_rng(11)
+    hot = rng.choice(num_rows, size=60000, replace=False)
+    out = torch.empty((n, dim), dtype=torch.float32, device="cuda")
+    for step in range(8):
+        idx = np.unique(np.concatenate([rng.choice(hot, size=n // 2, replace=False), rng.choice(num_rows, size=n, replace=False)]))
+        idx = idx[rng.permutation(len(idx))][:n].astype(np.int64)
+        d_idx = torch.from_numpy(idx).cuda()
+        cache.read_feature(out.data_ptr(), d_idx.data_ptr(), len(idx))
+        orc.read_feature(idx, oracle.SCHED_HITS_FIRST, want_rows=False)
+        assert cache.stats()[:2] == (orc.hit_cnt, orc.miss_cnt), f"step {step}"
+        assert torch.equal(out[: len(idx)], feature_rows_torch(d_idx, dim, 9))
+    keys, cnt, _ = cache.dump()
+    assert np.array_equal(keys, orc.keys()) and np.array_equal(cnt, orc.set_cnt())
+    assert orc.hit_cnt > 50000
+    cache.close()
+    table.close()
+
+
+@pytest.mark.parametrize("name,dim,cache_mb,n,num_rows", [
+    ("papers100M 15,10,5 (config 4)", 128, 16384, 1024 * 16 * 11 * 6, 24_000_000),    # 1,081,344 rows per minibatch
+    ("IGB-large 10,10,10 (config 5)", 1024, 16384, 1024 * 11 * 11 * 11, 4_000_000),     # 1,362,944 rows = 5.58 GB out
+])
+def test_full_size_big_configs_properties(hiplib, oracle, torch_cuda, name, dim, cache_mb, n, num_rows):
+    """Largest per-minibatch shapes of BASELINE.json (16 GiB caches) through size-independent properties: rows bit-equal
+    to the procedural table (checked in slices on the GPU), hits + misses == N, second pass all hits, counters equal the
+    tag-only oracle.  Exercises the > 4 GiB output offsets and the 2^20+ row batches."""
+    torch = torch_cuda
+    P = hiplib
+    from COALA_GNN.synthetic import alloc_pinned_table, feature_rows_torch
+    table = alloc_pinned_table(num_rows, dim, seed=4, device=0)
+    ctrl = P.SSD_GNN_SSD_Controllers(1, 4096, 1024, 0, 0, dim, True)
+    cache = P.Isolated_Cache(ctrl, None, 0, 1, cache_mb, table.device_ptr, num_rows=num_rows)
+    g = cache.geometry()
+    assert g.num_sets == oracle.num_sets(cache_mb, oracle.cache_dim(dim))
+    orc = oracle.OracleCache(cache_mb, dim, np.zeros((1, dim), dtype=np.float32), tag_only=True)
+    ids = torch.randperm(num_rows, generator=torch.Generator().manual_seed(3))[:n]
+    d_idx = ids.cuda()
+    out = torch.empty((n, dim), dtype=torch.float32, device="cuda")
+
+    def check_rows():
+        for lo in range(0, n, 1 << 18):
+            hi = min(n, lo + (1 << 18))
+            assert torch.equal(out[lo:hi], feature_rows_torch(d_idx[lo:hi], dim, 4))
+
+    for pass_no in range(2):
+        out.fill_(-1.0)
+        cache.read_feature(out.data_ptr(), d_idx.data_ptr(), n)
+        orc.read_feature(ids.numpy(), oracle.SCHED_HITS_FIRST, want_rows=False)
+        check_rows()
+        hit, miss, bad = cache.stats()
+        assert (hit, miss, bad) == (orc.hit_cnt, orc.miss_cnt, 0)
+        assert hit + miss == (pass_no + 1) * n
+    assert orc.hit_cnt > 0.99 * n  # second pass: (almost) everything was kept (a set overflows only past 32 ids)
+    cache.close()
+    table.close()

@@ -237,7 +237,7 @@ def main():
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu_baseline = run_cpu_baseline(args, host_array, batches[args.warmup:], fanout)
+        cpu_baseline = run_cpu_baseline(args, host_array, batches[args.warmup:], fanout, graph, seeds_for)
 
     if rank == 0:
         line = {
@@ -314,9 +314,10 @@ def _pmc_traffic():
         return None
 
 
-def run_cpu_baseline(args, host_array, batches, fanout):
+def run_cpu_baseline(args, host_array, batches, fanout, graph=None, seeds_for=None):
     """The CPU oracle (oracle/coala_oracle.c: a port, the reference itself cannot be built here) on one host core,
-    over a bounded sample of the same minibatches."""
+    over a bounded sample of the same minibatches.  Also timed beside it, as BASELINE.md section 5 asks: the oracle's
+    sampler twin (one core) and torch.index_select over the host table with every core (DGL is not installed)."""
     from oracle import oracle as O
     nb = min(args.cpu_baseline_batches, len(batches))
     if nb == 0:
@@ -325,16 +326,38 @@ def run_cpu_baseline(args, host_array, batches, fanout):
     orc = O.OracleCache(args.cache_mb, args.dim, host_array)
     t0 = time.perf_counter()
     rows = 0
-    for ids in idx_host:
+    i = 0
+    while time.perf_counter() - t0 < 12.0:  # a bounded ~12 s sample: the same minibatches, cycled
+        ids = idx_host[i % nb]
         orc.read_feature(ids, O.SCHED_HITS_FIRST)
         rows += len(ids)
-        if time.perf_counter() - t0 > 30.0:
-            break
+        i += 1
     dt = time.perf_counter() - t0
     orc.close()
-    return {"value": round(rows * args.dim * 4 / dt / 1e9, 3), "unit": "GB/s", "cores": 1, "kind": "port",
-            "sample": f"{rows} rows of the first minibatches of the timed region through the C oracle (cold oracle cache), {dt:.1f}s",
-            "host_cpus": os.cpu_count()}
+    res = {"value": round(rows * args.dim * 4 / dt / 1e9, 3), "unit": "GB/s", "cores": 1, "kind": "port",
+           "sample": f"{rows} rows ({i} minibatches of the timed region, cycled) through the C oracle from a cold cache, {dt:.1f}s",
+           "host_cpus": os.cpu_count()}
+    try:  # all-core gather: torch CPU index_select over the same pinned table
+        t = torch.from_numpy(host_array)
+        k = min(nb, 40)
+        t0 = time.perf_counter()
+        r2 = 0
+        for ids in idx_host[:k]:
+            torch.index_select(t, 0, torch.from_numpy(ids))
+            r2 += len(ids)
+        dt2 = time.perf_counter() - t0
+        res["index_select_all_cores"] = {"value": round(r2 * args.dim * 4 / dt2 / 1e9, 3), "unit": "GB/s", "threads": torch.get_num_threads(),
+                                         "ms_per_minibatch": round(dt2 / k * 1e3, 3)}
+    except Exception as e:  # noqa: BLE001
+        res["index_select_all_cores"] = {"error": str(e)[:100]}
+    if graph is not None and seeds_for is not None:  # CPU sampler (the oracle's twin of coala_sampler.hip), one core
+        ip, ix = graph.indptr.cpu().numpy(), graph.indices.cpu().numpy()
+        k = 20
+        t0 = time.perf_counter()
+        for s in range(k):
+            O.sample_blocks(ip, ix, seeds_for(s).cpu().numpy(), list(reversed(fanout)), args.seed, s)
+        res["sampler_twin_one_core_ms_per_minibatch"] = round((time.perf_counter() - t0) / k * 1e3, 3)
+    return res
 
 
 if __name__ == "__main__":

@@ -82,3 +82,36 @@ def test_dataloader_epoch_and_sage_step(hiplib, oracle, tmp_path, backend, metho
     assert cc[0] == -cc[1:].sum()                                                 # colour 0 absorbed the first-touch decrements
     del loader
     table.close()
+
+
+def test_shared_csc_dataset_from_npy(hiplib, oracle, tmp_path):
+    """Row f-4: the reference's on-disk layout (csc_indptr/csc_indices/node_feat/node_label_19 .npy) -> shm cold tier + HBM CSC."""
+    import torch
+    from COALA_GNN import MPI_Comm_Manager
+    from COALA_GNN.datasets import SharedCSCDataset
+    from COALA_GNN.sampler import NeighborSampler
+    rng = np.random.default_rng(0)
+    n, dim = 3000, 64
+    deg = rng.integers(1, 9, size=n)
+    indptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    indices = rng.integers(0, n, size=int(indptr[-1])).astype(np.int64)
+    feat = oracle.make_features(n, dim, seed=6)
+    np.save(tmp_path / "csc_indptr.npy", indptr); np.save(tmp_path / "csc_indices.npy", indices)
+    np.save(tmp_path / "node_feat.npy", feat); np.save(tmp_path / "node_label_19.npy", (np.arange(n) % 19).astype(np.int64))
+    comm = MPI_Comm_Manager(0)
+    comm.initialize_nested_process_group("isolated")
+    ds = SharedCSCDataset(str(tmp_path), comm, "cuda:0", shm_name=f"/coala_ds_test_{os.getpid()}")
+    g = ds[0]
+    assert (g.num_nodes, g.num_edges, ds.dim) == (n, len(indices), dim)
+    assert int(g.ndata["train_mask"].sum()) == int(0.6 * n)
+    assert np.array_equal(ds.feat_data[::37].cpu().numpy(), feat[::37])
+    P = hiplib
+    ctrl = P.SSD_GNN_SSD_Controllers(1, 4096, 1024, 0, 0, dim, True)
+    cache = P.Isolated_Cache(ctrl, None, 0, 1, 1, ds.feat_data.data_ptr(), num_rows=n)
+    inp, _, blocks = NeighborSampler([3, 3], seed=1).sample(g, torch.arange(0, 300, device="cuda"))
+    out = torch.empty((inp.numel(), dim), dtype=torch.float32, device="cuda")
+    cache.read_feature(out.data_ptr(), inp.data_ptr(), inp.numel())
+    assert np.array_equal(out.cpu().numpy(), feat[inp.cpu().numpy()])
+    assert torch.equal(blocks[-1].dstdata["labels"], torch.arange(0, 300, device="cuda") % 19)
+    cache.close()
+    ds.close()

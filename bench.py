@@ -195,7 +195,7 @@ def main():
     achieved = (alg_bytes / launches) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     roofline = {
         "bound": "hbm", "kernel": "probe_gather_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": _pmc_traffic(),
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": _pmc_traffic(args, world),
         "avg_launch_us": round(k_ms * 1e3, 2), "launches": int(prof.gather_launches),
         "rows_per_launch": round(prof.gather_rows / launches, 1), "hits_per_launch": round(prof.gather_hits / launches, 1),
         "alg_bytes_per_launch": int(alg_bytes / launches),
@@ -304,8 +304,13 @@ def run_epoch_leg(args, comm, graph, sampler, table, device, fanout, steps_per_e
     return out
 
 
-def _pmc_traffic():
-    """HBM bytes per launch of the probe+gather kernel from the committed rocprofv3 PMC pass (profiles/), or None."""
+def _pmc_traffic(args, world):
+    """HBM bytes per launch of the probe+gather kernel from the committed rocprofv3 PMC pass of THIS workload
+    (tools/profile_round.sh -> profiles/pmc_probe_gather.json: separate --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 as
+    MI355X_MICROARCH.md prescribes for gfx950), or None when the command line is not the profiled default."""
+    default = (args.rows, args.dim, args.fanout, args.batch, args.cache_mb, args.mode, world) == (10_000_000, 1024, "5,5", 1024, 4096, "minibatch", 1)
+    if not default:
+        return None
     path = os.path.join(ROOT, "profiles", "pmc_probe_gather.json")
     try:
         with open(path) as f:

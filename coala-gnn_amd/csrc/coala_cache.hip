@@ -442,39 +442,31 @@ __global__ __launch_bounds__(256) void route_count_kernel(const int64_t* __restr
     if ((uint32_t)lane < n_parts) wave_counts[tile * n_parts + lane] = mine;
 }
 
-// One block: exclusive scan of wave_counts over tiles for every owner, bucket totals and bucket bases.
+// One block, one wave per owner column (looping when there are more owners than waves): wave-level exclusive scan of
+// wave_counts over the tiles with a running carry, then bucket totals and bucket bases.
 __global__ __launch_bounds__(1024) void route_scan_kernel(uint32_t* __restrict__ wave_counts, int64_t n_tiles, uint32_t n_parts,
                                                           int64_t bucket_stride, int64_t* __restrict__ counts_out,
                                                           int64_t* __restrict__ offsets_out, int64_t* __restrict__ bases) {
-    __shared__ uint32_t part[1024];
     __shared__ int64_t totals[64];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t nthr = blockDim.x;
-    for (uint32_t g = 0; g < n_parts; ++g) {
-        const int64_t per = (n_tiles + nthr - 1) / nthr;
-        const int64_t lo = (int64_t)tid * per;
-        const int64_t hi = lo + per < n_tiles ? lo + per : n_tiles;
-        uint32_t s = 0;
-        for (int64_t t = lo; t < hi; ++t) s += wave_counts[t * n_parts + g];
-        part[tid] = s;
-        __syncthreads();
-        // Hillis-Steele inclusive scan over the block
-        for (uint32_t off = 1; off < nthr; off <<= 1) {
-            uint32_t v = (tid >= off) ? part[tid - off] : 0;
-            __syncthreads();
-            part[tid] += v;
-            __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const uint32_t n_waves = blockDim.x >> 6;
+    for (uint32_t g = threadIdx.x >> 6; g < n_parts; g += n_waves) {
+        uint32_t carry = 0;
+        for (int64_t t0 = 0; t0 < n_tiles; t0 += 64) {
+            const int64_t t = t0 + lane;
+            const uint32_t c = (t < n_tiles) ? wave_counts[t * n_parts + g] : 0u;
+            uint32_t incl = c;
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t v = __shfl_up(incl, off);
+                if (lane >= off) incl += v;
+            }
+            if (t < n_tiles) wave_counts[t * n_parts + g] = carry + incl - c; // exclusive offset of this tile inside bucket g
+            carry += __shfl(incl, 63);
         }
-        uint32_t run = part[tid] - s; // exclusive prefix of this thread's segment
-        for (int64_t t = lo; t < hi; ++t) {
-            const uint32_t cnt = wave_counts[t * n_parts + g];
-            wave_counts[t * n_parts + g] = run;
-            run += cnt;
-        }
-        if (tid == nthr - 1) totals[g] = part[tid];
-        __syncthreads();
+        if (lane == 0) totals[g] = (int64_t)carry;
     }
-    if (tid == 0) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
         int64_t acc = 0;
         for (uint32_t g = 0; g < n_parts; ++g) {
             counts_out[g] = totals[g];
@@ -844,7 +836,7 @@ int coala_cache_route(coala_cache_t* h, const int64_t* idx, int64_t n, int n_par
     const int blocks = (int)((n_tiles + 3) / 4);
     if (n_tiles > 0)
         hipLaunchKernelGGL(route_count_kernel, dim3(blocks), dim3(256), 0, s, idx, n, (uint32_t)n_parts, pshift, h->wave_counts, n_tiles);
-    hipLaunchKernelGGL(route_scan_kernel, dim3(1), dim3(1024), 0, s, h->wave_counts, n_tiles, (uint32_t)n_parts, bucket_stride,
+    hipLaunchKernelGGL(route_scan_kernel, dim3(1), dim3(64 * (n_parts < 16 ? n_parts : 16)), 0, s, h->wave_counts, n_tiles, (uint32_t)n_parts, bucket_stride,
                        counts_out, offsets_out, h->route_bases);
     if (n_tiles > 0)
         hipLaunchKernelGGL(route_scatter_kernel, dim3(blocks), dim3(256), 0, s, idx, n, (uint32_t)n_parts, pshift, h->wave_counts,

@@ -52,6 +52,9 @@ def parse_args():
     ap.add_argument("--no-allhit", action="store_true", help="skip the extra all-hit leg of the probe+gather kernel")
     ap.add_argument("--allhit-launches", type=int, default=100)
     ap.add_argument("--epoch-steps", type=int, default=150, help="steps of the end-to-end leg (loader + GraphSAGE step); 0 = skip")
+    ap.add_argument("--cold-tier", type=str, default="host", choices=["host", "hbm"],
+                    help="host: pinned host memory, zero-copy over PCIe (the workload BASELINE.json names). hbm: the whole table "
+                         "resident in this GPU's 288 GB HBM (not the headline configuration; MI355X placement data point)")
     ap.add_argument("--seed", type=int, default=0)
     return ap.parse_args()
 
@@ -81,7 +84,7 @@ def main():
         entry._load_build_module().build_lib()
     from COALA_GNN import MPI_Comm_Manager
     from COALA_GNN.COALA_GNN_Manager import COALA_GNN_Manager
-    from COALA_GNN.synthetic import PinnedFeatureTable, fill_table, fill_table_partition, powerlaw_csc
+    from COALA_GNN.synthetic import PinnedFeatureTable, feature_rows_torch, fill_table, fill_table_partition, powerlaw_csc
     from COALA_GNN.sampler import NeighborSampler
 
     backend = args.backend or ("isolated" if world == 1 else "nccl")
@@ -92,7 +95,28 @@ def main():
     t0 = time.time()
     nbytes = args.rows * args.dim * 4
     cold_partitioned = False
-    if world == 1 or backend == "isolated":
+    if args.cold_tier == "hbm":
+        class _HbmTable:  # same duck type as PinnedFeatureTable for COALA_GNN_Manager (data_ptr)
+            def __init__(self, rows, dim, stride=1, first=0):  # row k holds node id k*stride + first
+                self.t = torch.empty((rows, dim), dtype=torch.float32, device=device)
+                for lo in range(0, rows, 1 << 20):
+                    hi = min(rows, lo + (1 << 20))
+                    feature_rows_torch(torch.arange(lo, hi, device=device) * stride + first, dim, args.seed, out=self.t[lo:hi])
+                self.array = None
+
+            def data_ptr(self):
+                return self.t.data_ptr()
+
+            def close(self):
+                self.t = None
+        if world > 1 and backend != "isolated":  # every owner keeps its shard of the table in its own HBM
+            table = _HbmTable((args.rows + world - 1) // world, args.dim, world, comm.local_rank)
+            cold_partitioned = True
+            nbytes = ((args.rows + world - 1) // world) * args.dim * 4
+        else:
+            table = _HbmTable(args.rows, args.dim)
+        host_array = None
+    elif world == 1 or backend == "isolated":
         # the whole table, private to this rank (an isolated cache may read any row)
         table = PinnedFeatureTable(args.rows, args.dim, local_rank)
         fill_table(table.cpu_tensor, args.seed, device=device)
@@ -236,7 +260,7 @@ def main():
         epoch = run_epoch_leg(args, comm, graph, sampler, table, device, fanout, steps_per_epoch)
 
     cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and host_array is not None:
         cpu_baseline = run_cpu_baseline(args, host_array, batches[args.warmup:], fanout, graph, seeds_for)
 
     if rank == 0:
@@ -250,7 +274,7 @@ def main():
                                    f"mode={args.mode}",
                        "rows_per_step_per_gpu": round(rows_all / world / args.steps, 1),
                        "hit_ratio": round(hit_all / max(hit_all + miss_all, 1.0), 4),
-                       "cache_backend": backend, "cold_tier": "pinned host, owner-partitioned" if cold_partitioned else "pinned host",
+                       "cache_backend": backend, "cold_tier": "HBM" if args.cold_tier == "hbm" else ("pinned host, owner-partitioned" if cold_partitioned else "pinned host"),
                        "prewarm_steps": args.prewarm,
                        "steps_per_epoch": steps_per_epoch,
                        "epoch_time_s_fetch_only_extrapolated": round(ms_per_step * steps_per_epoch / 1e3, 2)},
@@ -308,7 +332,7 @@ def _pmc_traffic(args, world):
     """HBM bytes per launch of the probe+gather kernel from the committed rocprofv3 PMC pass of THIS workload
     (tools/profile_round.sh -> profiles/pmc_probe_gather.json: separate --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 as
     MI355X_MICROARCH.md prescribes for gfx950), or None when the command line is not the profiled default."""
-    default = (args.rows, args.dim, args.fanout, args.batch, args.cache_mb, args.mode, world) == (10_000_000, 1024, "5,5", 1024, 4096, "minibatch", 1)
+    default = (args.rows, args.dim, args.fanout, args.batch, args.cache_mb, args.mode, world, args.cold_tier) == (10_000_000, 1024, "5,5", 1024, 4096, "minibatch", 1, "host")
     if not default:
         return None
     path = os.path.join(ROOT, "profiles", "pmc_probe_gather.json")

@@ -76,8 +76,14 @@ def main():
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(local_rank)
-    device = f"cuda:{local_rank}"
+    # Test hook for the one-GPU development box: every rank drives GPU 0 and the exchange runs over gloo with host staging
+    # (RCCL cannot place two ranks on one device).  Never set by the driver; numbers from such a run are not a measurement.
+    single_dev = os.environ.get("COALA_BENCH_SINGLE_DEVICE") == "1"
+    dev_index = 0 if single_dev else local_rank
+    torch.cuda.set_device(dev_index)
+    device = f"cuda:{dev_index}"
+    if single_dev:
+        os.environ["COALA_CACHE_GROUP_BACKEND"] = "gloo"
 
     import __graft_entry__ as entry
     if rank == 0:
@@ -88,7 +94,8 @@ def main():
     from COALA_GNN.sampler import NeighborSampler
 
     backend = args.backend or ("isolated" if world == 1 else "nccl")
-    comm = MPI_Comm_Manager(0)                    # one machine: every rank in domain 0
+    comm = MPI_Comm_Manager(0, backend="gloo" if single_dev else None)   # one machine: every rank in domain 0
+    comm.device_index = dev_index
     comm.initialize_nested_process_group(backend)
 
     # ---------------------------------------------------------------- cold tier: fp32 [rows, dim] in pinned host memory
@@ -118,7 +125,7 @@ def main():
         host_array = None
     elif world == 1 or backend == "isolated":
         # the whole table, private to this rank (an isolated cache may read any row)
-        table = PinnedFeatureTable(args.rows, args.dim, local_rank)
+        table = PinnedFeatureTable(args.rows, args.dim, dev_index)
         fill_table(table.cpu_tensor, args.seed, device=device)
         host_array = table.array
     else:
@@ -126,7 +133,7 @@ def main():
         # (The reference maps ONE shared copy into every GPU: shared_UVA.cuh:42-100, available here as
         # Shared_UVA_Tensor_Manager; an owner of the partitioned cache never reads another owner's rows.)
         local_rows = (args.rows + world - 1) // world
-        table = PinnedFeatureTable(local_rows, args.dim, local_rank)
+        table = PinnedFeatureTable(local_rows, args.dim, dev_index)
         fill_table_partition(table.cpu_tensor, args.seed, comm.local_rank, world, device=device)
         host_array = None
         cold_partitioned = True
@@ -198,6 +205,8 @@ def main():
     prof = cache.profile()
     stat = torch.tensor([elapsed, float(rows_done), float(hit), float(miss)], dtype=torch.float64, device=device)
     if world > 1:
+        if single_dev:
+            stat = stat.cpu()
         tmax = stat.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(stat, op=dist.ReduceOp.SUM)
@@ -274,7 +283,7 @@ def main():
                                    f"mode={args.mode}",
                        "rows_per_step_per_gpu": round(rows_all / world / args.steps, 1),
                        "hit_ratio": round(hit_all / max(hit_all + miss_all, 1.0), 4),
-                       "cache_backend": backend, "cold_tier": "HBM" if args.cold_tier == "hbm" else ("pinned host, owner-partitioned" if cold_partitioned else "pinned host"),
+                       "cache_backend": backend, **({"TEST_HOOK_single_device": True} if single_dev else {}), "cold_tier": "HBM" if args.cold_tier == "hbm" else ("pinned host, owner-partitioned" if cold_partitioned else "pinned host"),
                        "prewarm_steps": args.prewarm,
                        "steps_per_epoch": steps_per_epoch,
                        "epoch_time_s_fetch_only_extrapolated": round(ms_per_step * steps_per_epoch / 1e3, 2)},

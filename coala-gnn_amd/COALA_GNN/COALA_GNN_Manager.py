@@ -52,8 +52,14 @@ class AllToAllExchange(object):
     (route, serve, scatter): a COALA_GNN_Pybind cache object in the product; tests may inject another provider to
     exercise this host logic with gloo on CPU tensors."""
 
-    def __init__(self, group, rank, world, dim, device):
+    def __init__(self, group, rank, world, dim, device, stage_through_host=None):
         self.group, self.rank, self.world, self.dim, self.device = group, rank, world, dim, device
+        # RCCL moves GPU tensors directly.  A gloo group cannot (no CUDA all-to-all): then the buffers are staged through
+        # host memory -- transport only, used by the multi-process tests on a one-GPU box; the kernels stay on the GPU.
+        if stage_through_host is None:
+            stage_through_host = (world > 1 and str(device).startswith("cuda") and dist.is_initialized()
+                                  and dist.get_backend(group) == "gloo")
+        self.stage_through_host = bool(stage_through_host)
         self._pending = None
         self.counts = torch.zeros(world, dtype=torch.int64, device=device)
         self.offsets = torch.zeros(world + 1, dtype=torch.int64, device=device)
@@ -64,6 +70,10 @@ class AllToAllExchange(object):
     def _a2a(self, out, inp, out_splits=None, in_splits=None):
         if self.world == 1:
             out.copy_(inp)
+        elif self.stage_through_host:
+            h_out = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_to_all_single(h_out, inp.cpu(), out_splits, in_splits, group=self.group)
+            out.copy_(h_out)
         else:
             dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
 
@@ -119,7 +129,8 @@ class COALA_GNN_Manager(object):
             num_rows = int(sim_buf.shape[0])
         sim_ptr = int(sim_buf.data_ptr())
 
-        device_id = MPI_comm_manager.local_rank
+        # the GPU this rank drives: its local rank, unless the topology object pins another ordinal (several ranks on one GPU)
+        device_id = getattr(MPI_comm_manager, "device_index", MPI_comm_manager.local_rank)
         self.SSD_Controllers = SSD_GNN_SSD_Controllers(num_ssds, page_size, num_elems, ssd_read_offset, device_id, dim,
                                                        self.is_simulation)
         self.max_sample_size = batch_size                     # :79-81

@@ -129,7 +129,8 @@ class MPI_Comm_Manager(object):
             self.local_gloo_gather_array.append(dist.new_group(ranks=members, backend="gloo"))
             if cache_backend in ("nccl", "nvshmem"):
                 # the reference builds this group only for "nccl" (:76-79); here "nvshmem" rides RCCL too
-                self.nccl_cache_gather_array.append(dist.new_group(ranks=members, backend="nccl" if use_cuda else "gloo"))
+                cache_be = os.environ.get("COALA_CACHE_GROUP_BACKEND", "nccl" if use_cuda else "gloo")
+                self.nccl_cache_gather_array.append(dist.new_group(ranks=members, backend=cache_be))
         self.local_gloo_gather = self.local_gloo_gather_array[self.master_process_index]
         self.local_gloo_scatter = self.local_gloo_scatter_array[self.master_process_index]
         if self.nccl_cache_gather_array:

@@ -19,6 +19,9 @@ class PinnedTable:
         self.array[...] = feat
         self.rows, self.dim = feat.shape
 
+    def data_ptr(self):  # what COALA_GNN_Manager reads from sim_buf
+        return self.device_ptr
+
     def close(self):
         if self.host_ptr:
             self.array = None

@@ -115,3 +115,23 @@ def test_manager_world1_gpu(hiplib, oracle, backend):
     assert mgr.get_aggregate_time() > 0
     del mgr
     table.close()
+
+
+@pytest.mark.parametrize("world,backend", [(2, "nccl"), (3, "nvshmem")])
+def test_partitioned_path_multi_process_one_gpu(world, backend):
+    """Real processes, real HIP kernels, owner-partitioned cold tier; transport = gloo with host staging (tests/_dist_gpu_worker.py)."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(here, "_dist_gpu_worker.py"), backend], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    for r, p in enumerate(procs):
+        out, _ = p.communicate(timeout=400)
+        assert p.returncode == 0 and f"rank {r} ok" in out, out[-3000:]

@@ -84,6 +84,16 @@ def main():
                 json.dump({"hbm_bytes_per_launch": int(fetch + write), "source": f"profiles/{ROUND}_{tag}_summary.json"}, f)
     with open(os.path.join(out_dir, f"{ROUND}_{tag}_summary.json"), "w") as f:
         json.dump(summary, f, indent=1)
+    # the GPU box only sends gpurun_out/ back (<= 64 MiB): mirror the small summaries there and drop the raw traces
+    if os.environ.get("GRAFT_REPO_ROOT"):
+        import shutil
+        mirror = os.path.join(ROOT, "gpurun_out", "profiles_out")
+        os.makedirs(mirror, exist_ok=True)
+        for name in os.listdir(out_dir):
+            if name.startswith(f"{ROUND}_{tag}_") or name == "pmc_probe_gather.json":
+                shutil.copy(os.path.join(out_dir, name), os.path.join(mirror, name))
+        for kind in ("trace", "fetch", "write"):
+            shutil.rmtree(os.path.join(ROOT, "gpurun_out", f"prof_{tag}_{kind}"), ignore_errors=True)
     print(json.dumps(summary, indent=1))
 
 

@@ -158,6 +158,7 @@ def main():
                                 num_rows=args.rows, profile=True, cold_partitioned=cold_partitioned)
     cache = manager.COALA_GNN_Cache
     max_rows = manager.max_sample_size
+    manager.sync_on_return = False  # stream-ordered fetches: the timed region is bracketed by synchronisations below
 
     total_steps = args.prewarm + args.warmup + args.steps
 

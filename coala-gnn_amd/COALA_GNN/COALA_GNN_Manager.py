@@ -122,6 +122,7 @@ class COALA_GNN_Manager(object):
         self.sim_buf = sim_buf
         self.is_simulation = sim_buf is not None
         self.aggregation_timer = 0.0
+        self.sync_on_return = True   # set False to keep fetch_feature fully stream-ordered (no host wait at all)
         if not self.is_simulation:
             raise RuntimeError("sim_buf is None: the NVMe/BaM tier is out of scope here; pass the pinned feature table "
                                "(the reference's --feat_cpu mode, used by every published script)")
@@ -144,14 +145,14 @@ class COALA_GNN_Manager(object):
             self.nvshmem_manager = NVSHMEM_Manager(0, MPI_comm_manager.local_rank)
             self.NVshmem_tensor_manager = NVShmem_Tensor_Manager(self.max_sample_size, dim, G, self.device)
             self.COALA_GNN_Cache = SSD_GNN_NVSHMEM_Cache(self.SSD_Controllers, dm, MPI_comm_manager.global_rank, G, cache_size,
-                                                         sim_ptr, num_rows=num_rows, profile=profile,
+                                                         sim_ptr, num_rows=num_rows, profile=profile, sync=False,
                                                          max_batch=self.max_sample_size, rank=MPI_comm_manager.local_rank,
                                                          cold_partitioned=cold_partitioned)
             self.exchange = AllToAllExchange(MPI_comm_manager.nccl_cache_gather, MPI_comm_manager.local_rank, G, dim, self.device)
             self.COALA_GNN_Cache.attach_exchange(self.exchange)
         elif self.cache_backend in ("isolated", "nccl"):      # :101-111
             self.COALA_GNN_Cache = Isolated_Cache(self.SSD_Controllers, dm, MPI_comm_manager.global_rank, G, cache_size,
-                                                  sim_ptr, num_rows=num_rows, profile=profile,
+                                                  sim_ptr, num_rows=num_rows, profile=profile, sync=False,
                                                   max_batch=self.max_sample_size, rank=MPI_comm_manager.local_rank,
                                                   cold_partitioned=cold_partitioned and self.cache_backend == "nccl")
             if cold_partitioned and self.cache_backend == "isolated":
@@ -185,6 +186,11 @@ class COALA_GNN_Manager(object):
         else:
             raise ValueError("Unsupported cache backend for fetch_feature")
         self._keep_index = index
+        # The native calls are enqueued on the current stream without synchronising (handles are created with sync=False:
+        # one host wait per minibatch instead of one per kernel group); like the reference, fetch_feature returns only when
+        # the rows are there, so the aggregation timer measures the whole fetch (COALA_GNN_Manager.py:122,134).
+        if self.sync_on_return:
+            torch.cuda.current_stream().synchronize()
         self.aggregation_timer += (time.time() - fetch_start)
         return (*batch, return_torch)
 

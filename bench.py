@@ -52,6 +52,8 @@ def parse_args():
     ap.add_argument("--no-allhit", action="store_true", help="skip the extra all-hit leg of the probe+gather kernel")
     ap.add_argument("--allhit-launches", type=int, default=100)
     ap.add_argument("--epoch-steps", type=int, default=150, help="steps of the end-to-end leg (loader + GraphSAGE step); 0 = skip")
+    ap.add_argument("--exchange", type=str, default=None, choices=["torch", "native"],
+                    help="N>1: torch.distributed all_to_all_single (default) or the fused native RCCL call")
     ap.add_argument("--cold-tier", type=str, default="host", choices=["host", "hbm"],
                     help="host: pinned host memory, zero-copy over PCIe (the workload BASELINE.json names). hbm: the whole table "
                          "resident in this GPU's 288 GB HBM (not the headline configuration; MI355X placement data point)")
@@ -155,7 +157,7 @@ def main():
     manager = COALA_GNN_Manager(node_distributor=None, num_ssds=1, page_size=args.dim * 4, num_elems=1024, ssd_read_offset=0,
                                 cache_size=args.cache_mb, batch_size=args.batch, fan_out=fanout, dim=args.dim,
                                 MPI_comm_manager=comm, device=device, cache_backend=backend, sim_buf=sim_ptr_owner,
-                                num_rows=args.rows, profile=True, cold_partitioned=cold_partitioned)
+                                num_rows=args.rows, profile=True, cold_partitioned=cold_partitioned, exchange=args.exchange)
     cache = manager.COALA_GNN_Cache
     max_rows = manager.max_sample_size
     manager.sync_on_return = False  # stream-ordered fetches: the timed region is bracketed by synchronisations below

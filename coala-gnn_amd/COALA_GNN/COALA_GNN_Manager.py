@@ -20,7 +20,7 @@ import torch.distributed as dist
 
 from COALA_GNN_Pybind import NVSHMEM_Manager, SSD_GNN_SSD_Controllers, SSD_GNN_NVSHMEM_Cache, Isolated_Cache
 
-__all__ = ["COALA_GNN_Manager", "NVShmem_Tensor_Manager", "AllToAllExchange"]
+__all__ = ["COALA_GNN_Manager", "NVShmem_Tensor_Manager", "AllToAllExchange", "NativeExchange"]
 
 
 class NVShmem_Tensor_Manager(object):
@@ -110,10 +110,59 @@ class AllToAllExchange(object):
         self.read_feature(ops, out_ptr, 0, max_index)
 
 
+class NativeExchange(object):
+    """The same exchange as AllToAllExchange, as ONE native call (coala_cache_fetch_distributed: route, ncclAllToAll of the
+    counts, ncclAllToAllv of ids and rows, serve, un-permute inside libcoala_hip.so).  Own RCCL communicator per cache
+    group, bootstrapped by broadcasting the 128-byte ncclUniqueId over a torch.distributed CPU group."""
+
+    def __init__(self, bootstrap_group, src_global_rank, rank, world, device_index):
+        import ctypes as C
+        from COALA_GNN_Pybind import _capi
+        self._capi, self._C = _capi, C
+        self._lib = _capi.load()
+        self.rank, self.world = rank, world
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            _capi.check(self._lib.coala_comm_unique_id(uid.data_ptr(), 128))
+        if world > 1:
+            dist.broadcast(uid, src=src_global_rank, group=bootstrap_group)
+        self._h = C.c_void_p()
+        _capi.check(self._lib.coala_comm_create(uid.data_ptr(), rank, world, int(device_index), C.byref(self._h)))
+        self.last_send_counts = self.last_recv_counts = None
+
+    def fetch(self, ops, out_ptr, idx_ptr, n, max_index=0):
+        from COALA_GNN_Pybind import current_stream
+        self._capi.check(self._lib.coala_cache_fetch_distributed(ops._h, self._h, int(out_ptr) or None, int(idx_ptr) or None, int(n),
+                                                                  current_stream()))
+        send = (self._C.c_int64 * self.world)()
+        recv = (self._C.c_int64 * self.world)()
+        self._lib.coala_comm_last_counts(self._h, send, recv)
+        self.last_send_counts, self.last_recv_counts = list(send), list(recv)
+
+    # SSD_GNN_NVSHMEM_Cache.send_requests / read_feature keep the reference's two-call sequence: the first call does it all
+    def send_requests(self, ops, idx_ptr, n, req_ptr, max_index):
+        self._pending = (idx_ptr, n)
+
+    def read_feature(self, ops, out_ptr, req_ptr, max_index):
+        idx_ptr, n = self._pending
+        self.fetch(ops, out_ptr, idx_ptr, n, max_index)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.coala_comm_destroy(self._h)
+            self._h = self._C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class COALA_GNN_Manager(object):
     def __init__(self, node_distributor, num_ssds, page_size, num_elems, ssd_read_offset, cache_size,  # MB
                  batch_size, fan_out, dim, MPI_comm_manager, device, cache_backend="nvshmem", sim_buf=None,
-                 num_rows=None, profile=False, cold_partitioned=False):
+                 num_rows=None, profile=False, cold_partitioned=False, exchange=None):
         self.node_distributor = node_distributor
         self.device = device
         self.cache_backend = cache_backend
@@ -141,6 +190,18 @@ class COALA_GNN_Manager(object):
         dm = None if node_distributor is None else node_distributor.distribute_manager
         G = MPI_comm_manager.local_size
         self.exchange = None
+        # "torch": torch.distributed all_to_all_single on the per-machine RCCL group (default).  "native": the fused C call
+        # with its own RCCL communicator (COALA_EXCHANGE=native).
+        import os
+        exchange = exchange or os.environ.get("COALA_EXCHANGE", "torch")
+        if exchange not in ("torch", "native"):
+            raise ValueError("exchange must be 'torch' or 'native'")
+
+        def make_exchange():
+            if exchange == "native":
+                return NativeExchange(MPI_comm_manager.local_gloo_gather, MPI_comm_manager.master_process_id,
+                                      MPI_comm_manager.local_rank, G, device_id)
+            return AllToAllExchange(MPI_comm_manager.nccl_cache_gather, MPI_comm_manager.local_rank, G, dim, self.device)
         if self.cache_backend == "nvshmem":                   # :83-99
             self.nvshmem_manager = NVSHMEM_Manager(0, MPI_comm_manager.local_rank)
             self.NVshmem_tensor_manager = NVShmem_Tensor_Manager(self.max_sample_size, dim, G, self.device)
@@ -148,7 +209,7 @@ class COALA_GNN_Manager(object):
                                                          sim_ptr, num_rows=num_rows, profile=profile, sync=False,
                                                          max_batch=self.max_sample_size, rank=MPI_comm_manager.local_rank,
                                                          cold_partitioned=cold_partitioned)
-            self.exchange = AllToAllExchange(MPI_comm_manager.nccl_cache_gather, MPI_comm_manager.local_rank, G, dim, self.device)
+            self.exchange = make_exchange()
             self.COALA_GNN_Cache.attach_exchange(self.exchange)
         elif self.cache_backend in ("isolated", "nccl"):      # :101-111
             self.COALA_GNN_Cache = Isolated_Cache(self.SSD_Controllers, dm, MPI_comm_manager.global_rank, G, cache_size,
@@ -158,7 +219,7 @@ class COALA_GNN_Manager(object):
             if cold_partitioned and self.cache_backend == "isolated":
                 raise ValueError("an isolated cache reads every row: it needs the whole cold table, not an owner's shard")
             if self.cache_backend == "nccl":
-                self.exchange = AllToAllExchange(MPI_comm_manager.nccl_cache_gather, MPI_comm_manager.local_rank, G, dim, self.device)
+                self.exchange = make_exchange()
         else:
             raise ValueError(f"Unsupported cache backend: {self.cache_backend}")  # the reference prints and returns (:113-115)
 

@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("COALA_HIP_LIB", os.path.join(os.path.dirname(_HERE), "lib", "libcoala_hip.so"))
 
-OK, EINVAL, EHIP, ENOMEM, EIO, EFORMAT, ERANGE = 0, -1, -2, -3, -4, -5, -6
+OK, EINVAL, EHIP, ENOMEM, EIO, EFORMAT, ERANGE, ECOMM = 0, -1, -2, -3, -4, -5, -6, -7
 FLAG_SYNC, FLAG_DISTRIBUTED, FLAG_PROFILE, FLAG_COLD_PARTITIONED = 1, 2, 4, 8
 WAYS = 32
 
@@ -46,6 +46,12 @@ SYMBOLS = {
     "coala_cache_serve": (_I, [_VP, _VP, _VP, _I64, _VP]),
     "coala_cache_route": (_I, [_VP, _VP, _I64, _I, _I64, _VP, _VP, _VP, _VP, _VP]),
     "coala_cache_scatter": (_I, [_VP, _VP, _VP, _VP, _I64, _VP]),
+    "coala_cache_row_dim": (_I64, [_VP]),
+    "coala_comm_unique_id": (_I, [_VP, _SZ]),
+    "coala_comm_create": (_I, [_VP, _I, _I, _I, C.POINTER(_VP)]),
+    "coala_comm_destroy": (_I, [_VP]),
+    "coala_comm_last_counts": (_I, [_VP, _VP, _VP]),
+    "coala_cache_fetch_distributed": (_I, [_VP, _VP, _VP, _VP, _I64, _VP]),
     "coala_cache_color_counts": (_I, [_VP, _VP, C.c_int32, _VP]),
     "coala_cache_stats": (_I, [_VP, C.POINTER(_U64), C.POINTER(_U64), C.POINTER(_U64), _I, _VP]),
     "coala_cache_dump": (_I, [_VP, _VP, _VP, _VP, _VP]),
@@ -93,7 +99,14 @@ def load():
         raise ImportError(
             f"libcoala_hip.so not found at {LIB_PATH}: build it with `python coala-gnn_amd/build.py` "
             "(hipcc --offload-arch=gfx950).  The product has no CPU fallback.")
-    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    # One HIP runtime and one RCCL per process: the PyTorch-ROCm wheel bundles its own libamdhip64.so / librccl.so (same
+    # SONAMEs as /opt/rocm's).  If torch is imported first, our NEEDED entries resolve to the copies it already loaded; the
+    # other order maps BOTH copies (seen as "double free or corruption" at exit).  So: torch first, whenever it is installed.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    L = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(L, name)  # AttributeError if the library does not export it
         fn.restype = res

@@ -5,7 +5,7 @@ import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("coala_cache.hip", "coala_sampler.hip", "coala_host.cpp", "coala_coloring.cpp")]
+SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("coala_cache.hip", "coala_sampler.hip", "coala_host.cpp", "coala_coloring.cpp", "coala_comm.cpp")]
 HEADERS = [os.path.join(_ROOT, "include", "coala_hip.h"), os.path.join(_HERE, "csrc", "coala_internal.h")]
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libcoala_hip.so")
@@ -35,7 +35,7 @@ def build_lib(force=False, verbose=False):
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", os.path.join(_ROOT, "include")]
-    cmd += sources() + ["-o", LIB_PATH + ".tmp", "-lrt"]
+    cmd += sources() + ["-o", LIB_PATH + ".tmp", "-lrt", "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

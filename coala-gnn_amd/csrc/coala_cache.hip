@@ -747,6 +747,8 @@ int coala_cache_destroy(coala_cache_t* h) {
     return COALA_OK;
 }
 
+int64_t coala_cache_row_dim(const coala_cache_t* h) { return h ? (int64_t)h->d.dim : 0; }
+
 int coala_cache_geometry(const coala_cache_t* h, coala_cache_geometry_t* out) {
     if (!h || !out) return fail(COALA_EINVAL, "null argument");
     out->num_sets = h->d.num_sets;

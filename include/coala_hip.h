@@ -28,6 +28,7 @@ extern "C" {
 #define COALA_EIO (-4)      /* file / shm failure                              */
 #define COALA_EFORMAT (-5)  /* malformed .npy                                  */
 #define COALA_ERANGE (-6)   /* an index was outside [0, num_rows)              */
+#define COALA_ECOMM (-7)    /* an RCCL call failed                             */
 
 #define COALA_WAYS 32u /* COALA_GNN_Modules/ssd_gnn_cache.cuh:61,204 */
 
@@ -114,6 +115,27 @@ int coala_cache_route(coala_cache_t* h, const int64_t* idx, int64_t n, int n_par
 /* out[map[r], 0:dim] = src[r, 0:dim] for r in [0, n).  Replaces Isolated_Cache::map_feat_data
  * (ssd_gnn_cache.cuh:327-356) / nccl_gather_feature_kernel + block_memcpy (cache_kernel.cu:113-137). */
 int coala_cache_scatter(coala_cache_t* h, float* out, const float* src, const int64_t* map, int64_t n, void* stream);
+
+/* Floats per row of the cold table / output (cfg.dim). */
+int64_t coala_cache_row_dim(const coala_cache_t* h);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Native fused fetch of the owner-partitioned cache over RCCL (one process per GPU, one communicator per cache group).
+ * Replaces, in one call: SSD_GNN_NVSHMEM_Cache::send_requests + read_feature (ssd_gnn_cache.cuh:111-174) and the "nccl"
+ * orchestration of COALA_GNN_Manager.fetch_feature (COALA-GNN-Setup/COALA_GNN/COALA_GNN_Manager.py:143-211):
+ * route -> ncclAllToAll(counts) -> one host read -> ncclAllToAllv(ids) -> serve -> ncclAllToAllv(rows) -> un-permute.
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct coala_comm coala_comm_t;
+/* ncclGetUniqueId: called by ONE rank; the 128 bytes are handed to the others by any side channel (torch.distributed). */
+int coala_comm_unique_id(void* out_id, size_t cap);
+/* ncclCommInitRank: collective over the nranks processes of the group. */
+int coala_comm_create(const void* id_bytes, int rank, int nranks, int device, coala_comm_t** out);
+int coala_comm_destroy(coala_comm_t* c);
+/* per-peer id counts of the last fetch (host int64[nranks] each, either may be NULL) */
+int coala_comm_last_counts(const coala_comm_t* c, int64_t* send, int64_t* recv);
+/* out[i, 0:dim] = row of idx[i], wherever its owner (idx[i] % nranks) is.  Collective: every rank of the communicator calls
+ * it once per step (n may be 0).  Synchronises `stream` once, in the middle (the counts); work after that is enqueued. */
+int coala_cache_fetch_distributed(coala_cache_t* h, coala_comm_t* c, float* out, const int64_t* idx, int64_t n, void* stream);
 
 /* Copy the colour occupancy counters to HOST memory dst[0 .. n_entries).  Replaces get_cache_data
  * (ssd_gnn_cache.cuh:176-186,270-280).  The reference copies num_colors entries; pass num_colors+1 to also get the

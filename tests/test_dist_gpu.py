@@ -84,8 +84,9 @@ def test_partitioned_cache_matches_oracle(hiplib, oracle, G, dim, cache_mb, cold
     table.close()
 
 
-@pytest.mark.parametrize("backend", ["isolated", "nccl", "nvshmem"])
-def test_manager_world1_gpu(hiplib, oracle, backend):
+@pytest.mark.parametrize("backend,exchange", [("isolated", None), ("nccl", "torch"), ("nvshmem", "torch"), ("nccl", "native"),
+                                              ("nvshmem", "native")])
+def test_manager_world1_gpu(hiplib, oracle, backend, exchange):
     """COALA_GNN_Manager.fetch_feature on one rank for every backend string: G = 1 degenerates to the isolated cache
     (SURVEY.md section 8e); the nccl/nvshmem flavours still run route -> exchange -> serve -> scatter."""
     import torch
@@ -98,8 +99,10 @@ def test_manager_world1_gpu(hiplib, oracle, backend):
     comm = MPI_Comm_Manager(0)
     comm.initialize_nested_process_group(backend)
     mgr = COALA_GNN_Manager(None, 1, dim * 4, 1024, 0, 8, 64, [5, 5], dim, comm, "cuda:0", cache_backend=backend,
-                            sim_buf=table, num_rows=rows)
+                            sim_buf=table, num_rows=rows, exchange=exchange)
     assert mgr.max_sample_size == 64 * 36
+    if exchange == "native":  # a real RCCL communicator of one rank: ncclAllToAll / ncclAllToAllv to self
+        assert type(mgr.exchange).__name__ == "NativeExchange"
     orc = oracle.OracleCache(8, dim, feat, n_gpus=1, distributed=backend != "isolated")
     rng = np.random.default_rng(1)
     for step in range(5):
@@ -112,6 +115,8 @@ def test_manager_world1_gpu(hiplib, oracle, backend):
         want = orc.read_feature(idx, oracle.SCHED_HITS_FIRST)
         assert got.cpu().numpy().tobytes() == want.tobytes()
         assert mgr.COALA_GNN_Cache.stats()[:2] == (orc.hit_cnt, orc.miss_cnt)
+        if mgr.exchange is not None:
+            assert mgr.exchange.last_send_counts == [2000] and mgr.exchange.last_recv_counts == [2000]
     assert mgr.get_aggregate_time() > 0
     del mgr
     table.close()

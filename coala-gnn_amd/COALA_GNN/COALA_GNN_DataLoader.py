@@ -127,7 +127,7 @@ class COALA_GNN_DataLoader(torch.utils.data.DataLoader):
             num_elems=SSD_info.num_elems, ssd_read_offset=SSD_info.ssd_read_offset, cache_size=cache_size,
             batch_size=batch_size, fan_out=fan_out, dim=dim, MPI_comm_manager=node_distributor.comm_manager, device=device,
             cache_backend=cache_backend, sim_buf=sim_buf, num_rows=num_rows, profile=profile,
-            cold_partitioned=cold_partitioned)
+            cold_partitioned=cold_partitioned, out_ring=self.prefetch + 2)  # batches alive at once: consumer + queue + producer
         self.scheduler = COALA_GNN_Node_Distribution_Scheduler(node_distributor=self.node_distributor,
                                                                ssd_gnn_manager=self.COALA_GNN_Manager,
                                                                refresh_counter=self.refresh_counter)

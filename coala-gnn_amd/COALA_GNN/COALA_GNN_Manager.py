@@ -162,7 +162,7 @@ class NativeExchange(object):
 class COALA_GNN_Manager(object):
     def __init__(self, node_distributor, num_ssds, page_size, num_elems, ssd_read_offset, cache_size,  # MB
                  batch_size, fan_out, dim, MPI_comm_manager, device, cache_backend="nvshmem", sim_buf=None,
-                 num_rows=None, profile=False, cold_partitioned=False, exchange=None):
+                 num_rows=None, profile=False, cold_partitioned=False, exchange=None, out_ring=2):
         self.node_distributor = node_distributor
         self.device = device
         self.cache_backend = cache_backend
@@ -204,7 +204,7 @@ class COALA_GNN_Manager(object):
             return AllToAllExchange(MPI_comm_manager.nccl_cache_gather, MPI_comm_manager.local_rank, G, dim, self.device)
         if self.cache_backend == "nvshmem":                   # :83-99
             self.nvshmem_manager = NVSHMEM_Manager(0, MPI_comm_manager.local_rank)
-            self.NVshmem_tensor_manager = NVShmem_Tensor_Manager(self.max_sample_size, dim, G, self.device)
+            self.NVshmem_tensor_manager = NVShmem_Tensor_Manager(self.max_sample_size, dim, G, self.device, ring=max(2, int(out_ring)))
             self.COALA_GNN_Cache = SSD_GNN_NVSHMEM_Cache(self.SSD_Controllers, dm, MPI_comm_manager.global_rank, G, cache_size,
                                                          sim_ptr, num_rows=num_rows, profile=profile, sync=False,
                                                          max_batch=self.max_sample_size, rank=MPI_comm_manager.local_rank,

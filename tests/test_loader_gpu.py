@@ -28,7 +28,7 @@ def test_shared_uva_two_processes_one_gpu():
 
 
 @pytest.mark.parametrize("backend,method,prefetch", [("isolated", "node_color", 0), ("nvshmem", "baseline", 0), ("isolated", "baseline", 2),
-                                                     ("nccl", "node_color", 1)])
+                                                     ("nccl", "node_color", 1), ("nvshmem", "baseline", 2)])
 def test_dataloader_epoch_and_sage_step(hiplib, oracle, tmp_path, backend, method, prefetch):
     import torch
     from COALA_GNN import COALA_GNN_DataLoader, MPI_Comm_Manager, Node_Distributor, SSD_INFO

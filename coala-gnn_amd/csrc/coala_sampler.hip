@@ -208,6 +208,53 @@ __global__ __launch_bounds__(kScanBlock) void assign_local_kernel(const int64_t*
     }
 }
 
+// A+B+C in one launch for small layers (<= kSmallItems items): one 1024-thread block walks the items tile by tile with a
+// running carry.  Saves two launches and two dependent kernel boundaries per layer where the work is a few microseconds.
+constexpr int kSmallItems = 1 << 13; // measured: above ~8k items the three parallel kernels win over one block
+__global__ __launch_bounds__(1024) void flag_scan_assign_small_kernel(const int64_t* __restrict__ dst, const int64_t* __restrict__ nbr,
+                                                                      const int64_t* __restrict__ n_dst_dev, int fanout,
+                                                                      const uint32_t* __restrict__ slot_of_item,
+                                                                      const uint32_t* __restrict__ minpos,
+                                                                      uint32_t* __restrict__ local_of_slot, int64_t* __restrict__ src_nodes,
+                                                                      int64_t* __restrict__ n_src_out) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t s_carry;
+    const int64_t n_dst = *n_dst_dev;
+    const int64_t n_items = n_dst * (fanout + 1);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    constexpr int IT = 4;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int64_t tile0 = 0; tile0 < n_items; tile0 += 1024 * IT) {
+        const int64_t base = tile0 + (int64_t)threadIdx.x * IT;
+        uint32_t f[IT];
+        uint32_t c = 0;
+        for (int i = 0; i < IT; ++i) { f[i] = first_flag(slot_of_item, minpos, base + i, n_items); c += f[i]; }
+        uint32_t incl = c;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = __shfl_up(incl, off);
+            if (lane >= off) incl += v;
+        }
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        uint32_t wbase = s_carry;
+        for (int q = 0; q < w; ++q) wbase += wsum[q];
+        uint32_t run = wbase + incl - c;
+        for (int i = 0; i < IT; ++i) {
+            if (f[i]) {
+                const int64_t p = base + i;
+                src_nodes[run] = item_key(dst, nbr, n_dst, p);
+                local_of_slot[slot_of_item[p]] = run;
+                ++run;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = run; // last thread's running index == total so far
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_src_out = (int64_t)s_carry;
+}
+
 // S4: neighbour -> local index in the source list.
 __global__ __launch_bounds__(256) void relabel_kernel(const int64_t* __restrict__ n_dst_dev, int fanout, const uint32_t* __restrict__ slot_of_item,
                                                       const uint32_t* __restrict__ local_of_slot, int32_t* __restrict__ nbr_local) {
@@ -313,10 +360,9 @@ int coala_sampler_sample(coala_sampler_t* s, const int64_t* seeds, int64_t n_see
     if ((rc = grow((void**)&s->tile_sums, &s->tile_cap, max_items / kScanTile + 2, sizeof(uint32_t), st))) return rc;
     if (table > s->table_cap) {
         HIPCHK(hipStreamSynchronize(st));
-        for (void** p : {(void**)&s->keys, (void**)&s->minpos, (void**)&s->local_of_slot})
+        for (void** p : {(void**)&s->keys, (void**)&s->local_of_slot})
             if (*p) { HIPCHK(hipFree(*p)); *p = nullptr; }
-        HIPCHK(hipMalloc((void**)&s->keys, table * sizeof(long long)));
-        HIPCHK(hipMalloc((void**)&s->minpos, table * sizeof(uint32_t)));
+        HIPCHK(hipMalloc((void**)&s->keys, table * (sizeof(long long) + sizeof(uint32_t)))); // keys + first-position words
         HIPCHK(hipMalloc((void**)&s->local_of_slot, table * sizeof(uint32_t)));
         s->table_cap = table;
     }
@@ -336,17 +382,24 @@ int coala_sampler_sample(coala_sampler_t* s, const int64_t* seeds, int64_t n_see
         while (tbl < 2 * (uint64_t)items_cap) tbl *= 2;
         const uint32_t mask = (uint32_t)(tbl - 1);
         const int64_t* n_dst_dev = s->counts_dev + l;
-        HIPCHK(hipMemsetAsync(s->keys, 0xFF, tbl * sizeof(long long), st));
-        HIPCHK(hipMemsetAsync(s->minpos, 0xFF, tbl * sizeof(uint32_t), st));
+        // keys (8 B) and first-position words (4 B) of this layer's table sit back to back: one 0xFF fill clears both
+        long long* keys = s->keys;
+        uint32_t* minpos = reinterpret_cast<uint32_t*>(s->keys + tbl);
+        HIPCHK(hipMemsetAsync(keys, 0xFF, tbl * (sizeof(long long) + sizeof(uint32_t)), st));
         hipLaunchKernelGGL(sample_layer_kernel, dim3(grid1d(cap, 256, 4096)), dim3(256), 0, st, s->indptr, s->indices, dst, n_dst_dev, f,
                            seed, step, l, s->num_nodes, s->nbr_global);
         hipLaunchKernelGGL(hash_insert_kernel, dim3(grid1d(items_cap, 256, 8192)), dim3(256), 0, st, dst, s->nbr_global, n_dst_dev, f,
-                           s->keys, s->minpos, mask, s->slot_of_item);
-        const int tiles = grid1d(items_cap, kScanTile, 4096);
-        hipLaunchKernelGGL(flag_count_kernel, dim3(tiles), dim3(kScanBlock), 0, st, n_dst_dev, f, s->slot_of_item, s->minpos, s->tile_sums);
-        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, n_dst_dev, f, s->tile_sums, s->counts_dev + l + 1);
-        hipLaunchKernelGGL(assign_local_kernel, dim3(tiles), dim3(kScanBlock), 0, st, dst, s->nbr_global, n_dst_dev, f, s->slot_of_item,
-                           s->minpos, s->tile_sums, s->local_of_slot, src_nodes_out[l]);
+                           keys, minpos, mask, s->slot_of_item);
+        if (items_cap <= kSmallItems) {
+            hipLaunchKernelGGL(flag_scan_assign_small_kernel, dim3(1), dim3(1024), 0, st, dst, s->nbr_global, n_dst_dev, f, s->slot_of_item,
+                               minpos, s->local_of_slot, src_nodes_out[l], s->counts_dev + l + 1);
+        } else {
+            const int tiles = grid1d(items_cap, kScanTile, 4096);
+            hipLaunchKernelGGL(flag_count_kernel, dim3(tiles), dim3(kScanBlock), 0, st, n_dst_dev, f, s->slot_of_item, minpos, s->tile_sums);
+            hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, n_dst_dev, f, s->tile_sums, s->counts_dev + l + 1);
+            hipLaunchKernelGGL(assign_local_kernel, dim3(tiles), dim3(kScanBlock), 0, st, dst, s->nbr_global, n_dst_dev, f, s->slot_of_item,
+                               minpos, s->tile_sums, s->local_of_slot, src_nodes_out[l]);
+        }
         hipLaunchKernelGGL(relabel_kernel, dim3(grid1d(cap * f, 256, 8192)), dim3(256), 0, st, n_dst_dev, f, s->slot_of_item,
                            s->local_of_slot, nbr_local_out[l]);
         dst = src_nodes_out[l];

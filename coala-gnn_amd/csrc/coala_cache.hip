@@ -112,14 +112,18 @@ struct Geo {
 // that K2 walks is pushed with one atomicExch on the set's own head word.  (Measured alternatives: a miss-list append
 // per chunk or per wave serialises at ~12 ns per same-address atomic -- 4096 waves = 49 us, as long as the whole hit
 // gather; a block-level append needs LDS staging and a trailing barrier and still costs 5-7 us.)
+#ifndef K1_MIN_WAVES
+#define K1_MIN_WAVES 4 // waves per SIMD the register allocator must leave room for
+#endif
 constexpr int kK1Waves = 2; // waves per block (measured: 2048 x 128 threads beats 1024 x 256 and 256 x 1024 by 3-20 %)
 
 template <typename V> __device__ __forceinline__ V nt_load(const V* p) { return __builtin_nontemporal_load(p); }
 template <typename V> __device__ __forceinline__ void nt_store(V v, V* p) { __builtin_nontemporal_store(v, p); }
 
-template <int CD, int VEC, int NP = 4>
-__global__ __launch_bounds__(64 * kK1Waves) void probe_gather_kernel(CacheDev c, const int64_t* __restrict__ idx,
+template <int CD, int VEC, int NP = 4, bool FULL = false>
+__global__ __launch_bounds__(64 * kK1Waves, K1_MIN_WAVES) void probe_gather_kernel(CacheDev c, const int64_t* __restrict__ idx,
                                                                     float* __restrict__ out, int64_t n, uint32_t gen) {
+    // FULL: dim == cache_dim, every lane of a row group moves data -> no per-lane bounds predicate around the row moves
     using G = Geo<CD, VEC, NP>;
     using V = typename VecT<VEC>::type;
     constexpr int R = G::R;
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(64 * kK1Waves) void probe_gather_kernel(CacheDev c,
 #pragma unroll
             for (int v = 0; v < G::VPL; ++v) {
                 const uint32_t u = v * G::LPR + l_in;
-                if (h && u < nunits) val[p][v] = nt_load(src + u);
+                if (h && (FULL || u < nunits)) val[p][v] = nt_load(src + u);
             }
         }
         // ---- tag sets of the next chunk go out behind the row loads
@@ -241,9 +245,9 @@ __global__ __launch_bounds__(64 * kK1Waves) void probe_gather_kernel(CacheDev c,
 #pragma unroll
             for (int v = 0; v < G::VPL; ++v) {
                 const uint32_t u = v * G::LPR + l_in;
-                if (u < nunits) {
+                if (FULL || u < nunits) {
                     if (h) nt_store(val[p][v], dst + u);
-                    else if (bad) dst[u] = V(0.0f); // rejected id: zero row
+                    else if (bad) dst[u] = V(0.0f); // rejected id: zero row (kept inline: hoisting it out costs 12 VGPRs and 10 % speed)
                 }
             }
         }
@@ -784,14 +788,18 @@ static int read_feature_impl(coala_cache_t* h, float* out, const int64_t* idx, i
         // K1: 2-wave blocks, every wave resident; grid-stride over the chunks
         {
             ProfScope ps(h, s, 0, (uint64_t)n);
+            const bool full = (VEC == 4) && ((int)d.dim == CD);
             if (h->k1_passes == 2) {
                 using G2 = Geo<CD, VEC, 2>;
                 const int64_t chunks2 = (n + G2::R - 1) / G2::R;
-                hipLaunchKernelGGL((probe_gather_kernel<CD, VEC, 2>), dim3(grid_for(chunks2, kK1Waves, h->k1_grid_cap)), dim3(64 * kK1Waves), 0,
-                                   s, d, idx, out, n, gen);
+                hipLaunchKernelGGL((probe_gather_kernel<CD, VEC, 2, false>), dim3(grid_for(chunks2, kK1Waves, h->k1_grid_cap)),
+                                   dim3(64 * kK1Waves), 0, s, d, idx, out, n, gen);
+            } else if (full) {
+                hipLaunchKernelGGL((probe_gather_kernel<CD, VEC, 4, true>), dim3(grid_for(chunks, kK1Waves, h->k1_grid_cap)),
+                                   dim3(64 * kK1Waves), 0, s, d, idx, out, n, gen);
             } else {
-                hipLaunchKernelGGL((probe_gather_kernel<CD, VEC, 4>), dim3(grid_for(chunks, kK1Waves, h->k1_grid_cap)), dim3(64 * kK1Waves), 0,
-                                   s, d, idx, out, n, gen);
+                hipLaunchKernelGGL((probe_gather_kernel<CD, VEC, 4, false>), dim3(grid_for(chunks, kK1Waves, h->k1_grid_cap)),
+                                   dim3(64 * kK1Waves), 0, s, d, idx, out, n, gen);
             }
         }
         {

@@ -104,6 +104,7 @@ def main():
     t0 = time.time()
     nbytes = args.rows * args.dim * 4
     cold_partitioned = False
+    rows_scale = 1.0
     if args.cold_tier == "hbm":
         class _HbmTable:  # same duck type as PinnedFeatureTable for COALA_GNN_Manager (data_ptr)
             def __init__(self, rows, dim, stride=1, first=0):  # row k holds node id k*stride + first
@@ -126,8 +127,20 @@ def main():
             table = _HbmTable(args.rows, args.dim)
         host_array = None
     elif world == 1 or backend == "isolated":
-        # the whole table, private to this rank (an isolated cache may read any row)
-        table = PinnedFeatureTable(args.rows, args.dim, dev_index)
+        # the whole table, private to this rank (an isolated cache may read any row).  If the host cannot pin that much
+        # memory, the node count is scaled down and the factor reported.
+        table = None
+        want_rows = args.rows
+        while table is None:
+            try:
+                table = PinnedFeatureTable(args.rows, args.dim, dev_index)
+            except RuntimeError as e:
+                if args.rows <= 1_000_000:
+                    raise
+                log(f"pinning {args.rows * args.dim * 4 / 1e9:.1f} GB failed ({e}); halving the node count")
+                args.rows //= 2
+        rows_scale = args.rows / want_rows
+        nbytes = args.rows * args.dim * 4
         fill_table(table.cpu_tensor, args.seed, device=device)
         host_array = table.array
     else:
@@ -287,7 +300,7 @@ def main():
                        "rows_per_step_per_gpu": round(rows_all / world / args.steps, 1),
                        "hit_ratio": round(hit_all / max(hit_all + miss_all, 1.0), 4),
                        "cache_backend": backend, **({"TEST_HOOK_single_device": True} if single_dev else {}), "cold_tier": "HBM" if args.cold_tier == "hbm" else ("pinned host, owner-partitioned" if cold_partitioned else "pinned host"),
-                       "prewarm_steps": args.prewarm,
+                       "prewarm_steps": args.prewarm, "rows_scale_factor": rows_scale,
                        "steps_per_epoch": steps_per_epoch,
                        "epoch_time_s_fetch_only_extrapolated": round(ms_per_step * steps_per_epoch / 1e3, 2)},
             "roofline": roofline,

@@ -39,6 +39,13 @@ def main():
     assert np.array_equal(mgr.get_host_array(np.float32, (rows, dim))[::997], feat[::997])
     got = uva[torch.arange(0, rows, 991, device="cuda")].cpu().numpy()   # GPU reads the alias (zero-copy)
     assert np.array_equal(got, feat[::991])
+    # the GPU-staged writer (Shared_Tensor.py:164-179) fills the same mapping
+    feat2 = O.make_features(rows, dim, seed=9)
+    mgr.write_np_array_gpu(uva, feat2, "cuda:0")
+    torch.cuda.synchronize()
+    comm.local_comm.Barrier()
+    assert np.array_equal(mgr.get_host_array(np.float32, (rows, dim))[::499], feat2[::499])
+    mgr.write_np_array(uva, feat)
     ctrl = P.SSD_GNN_SSD_Controllers(1, 4096, 1024, 0, 0, dim, True)
     cache = P.Isolated_Cache(ctrl, None, rank, 1, 4, uva.data_ptr(), num_rows=rows)
     orc = O.OracleCache(4, dim, feat)

@@ -140,3 +140,49 @@ def test_partitioned_path_multi_process_one_gpu(world, backend):
     for r, p in enumerate(procs):
         out, _ = p.communicate(timeout=400)
         assert p.returncode == 0 and f"rank {r} ok" in out, out[-3000:]
+
+
+def test_reference_call_sequence_nccl_helpers(hiplib, oracle):
+    """The reference's own "nccl" orchestration (COALA_GNN_Manager.py:143-211) replayed with its argument conventions on G
+    logical ranks: split_node_list into [G][max_sample] buffers, nccl_get_feature over per-peer id / row buffers,
+    map_feat_data with the [G][max_sample] meta buffer.  Exercises the pybind-mirror methods themselves."""
+    import torch
+    P = hiplib
+    G, dim, num_rows, cache_mb, max_sample = 3, 128, 9000, 1, 2048
+    feat = oracle.make_features(num_rows, dim, seed=21)
+    table = PinnedTable(P, feat)
+    ctrl = P.SSD_GNN_SSD_Controllers(1, 512, 1024, 0, 0, dim, True)
+    caches = [P.Isolated_Cache(ctrl, None, r, G, cache_mb, table.device_ptr, num_rows=num_rows, rank=r) for r in range(G)]
+    orcs = [oracle.OracleCache(cache_mb, dim, feat, n_gpus=G, distributed=True) for _ in range(G)]
+    rng = np.random.default_rng(2)
+    for step in range(4):
+        idx_np = [rng.choice(num_rows, size=int(rng.integers(1, max_sample)), replace=False).astype(np.int64) for _ in range(G)]
+        node = [torch.zeros(G * max_sample, dtype=torch.int64, device="cuda") for _ in range(G)]
+        mp = [torch.zeros(G * max_sample, dtype=torch.int64, device="cuda") for _ in range(G)]
+        cnt = [torch.zeros(G, dtype=torch.int64, device="cuda") for _ in range(G)]
+        idx = [torch.from_numpy(i).cuda() for i in idx_np]
+        for r in range(G):  # :152-153
+            caches[r].split_node_list(idx[r].data_ptr(), len(idx_np[r]), node[r].data_ptr(), mp[r].data_ptr(), cnt[r].data_ptr(), G, max_sample)
+        counts = [c.cpu().tolist() for c in cnt]
+        # all_to_all of the id buffers (:156-165): recv[o][s] = node[s][o*max : o*max + counts[s][o]]
+        outs = [torch.zeros((len(idx_np[r]), dim), dtype=torch.float32, device="cuda") for r in range(G)]
+        got_rows = [[None] * G for _ in range(G)]
+        for o in range(G):
+            recv = [node[s][o * max_sample: o * max_sample + counts[s][o]].clone() for s in range(G)]  # separate, non-contiguous buffers
+            gathered = [torch.zeros((counts[s][o], dim), dtype=torch.float32, device="cuda") for s in range(G)]  # :170-175
+            caches[o].nccl_get_feature([t.data_ptr() for t in recv], [t.data_ptr() for t in gathered], [counts[s][o] for s in range(G)], G, max_sample)
+            for s in range(G):
+                got_rows[s][o] = gathered[s]           # send/recv (:194-203)
+        for r in range(G):                            # :206-208 REMAP
+            caches[r].map_feat_data(outs[r].data_ptr(), [got_rows[r][o].data_ptr() for o in range(G)], mp[r].data_ptr(),
+                                    [counts[r][o] for o in range(G)], G, max_sample)
+            assert outs[r].cpu().numpy().tobytes() == feat[idx_np[r]].tobytes()
+        # separate per-peer buffers are served as one batch per peer, in peer order (documented in COALA_GNN_Pybind)
+        for o in range(G):
+            for s in range(G):
+                ids = idx_np[s][idx_np[s] % G == o]
+                orcs[o].read_feature(ids, oracle.SCHED_HITS_FIRST, want_rows=False)
+            assert caches[o].stats()[:2] == (orcs[o].hit_cnt, orcs[o].miss_cnt)
+    for c in caches:
+        c.close()
+    table.close()

@@ -85,6 +85,71 @@ __global__ __launch_bounds__(1024) void probe_gather_v2(CacheDev c, const int64_
     }
 }
 
+// ---------------------------------------------------------------- experimental variant: rows staged through LDS by LDS-DMA
+// (global_load_lds: per-lane source address, wave-contiguous LDS destination), then ds_read_b128 -> global_store.
+template <int ROWS, bool NT>
+__global__ __launch_bounds__(128) void probe_gather_lds(CacheDev c, const int64_t* __restrict__ idx, float* __restrict__ out,
+                                                        int64_t n, uint32_t gen) {
+    constexpr int CD = 1024;
+    __shared__ __attribute__((aligned(16))) vfloat4 stage[2][ROWS][256];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t wave = (int64_t)blockIdx.x * 2 + w;
+    const int64_t n_waves = (int64_t)gridDim.x * 2;
+    const int64_t n_chunks = (n + ROWS - 1) / ROWS;
+    auto load_id = [&](int64_t ch) -> uint64_t {
+        const int64_t i_l = ch * ROWS + (lane >> 4);
+        return (ch < n_chunks && (lane >> 4) < ROWS && i_l < n) ? (uint64_t)idx[i_l] : 0xFFFFFFFFFFFFFFFFull;
+    };
+    int64_t chunk = wave;
+    uint64_t id = load_id(chunk), id_next = load_id(chunk + n_waves);
+    bool ok = id < c.num_rows;
+    uint64_t set = ok ? set_of(c, id) : 0;
+    vu64x2 kk = {kEmptyKey, kEmptyKey};
+    if (ok) kk = *reinterpret_cast<const vu64x2*>(c.keys + set * COALA_WAYS + (lane & 15) * 2);
+    for (; chunk < n_chunks; chunk += n_waves) {
+        const int64_t base = chunk * ROWS;
+        const uint64_t m0 = __ballot(ok && kk.x == id), m1 = __ballot(ok && kk.y == id);
+        uint32_t slot[ROWS];
+        uint32_t hitmask = 0;
+#pragma unroll
+        for (int q = 0; q < ROWS; ++q) {
+            const uint32_t a = (uint32_t)(m0 >> (16 * q)) & 0xFFFFu, b = (uint32_t)(m1 >> (16 * q)) & 0xFFFFu, mm = a | b;
+            const uint64_t set_q = readlane64(set, 16 * q);
+            uint32_t way = 0;
+            if (mm) { const int j = __builtin_ctz(mm); way = 2 * j + (((a >> j) & 1) ? 0 : 1); hitmask |= 1u << q; }
+            slot[q] = (uint32_t)(set_q * COALA_WAYS) + way;
+        }
+        const uint64_t id_next2 = load_id(chunk + 2 * n_waves);
+#pragma unroll
+        for (int p = 0; p < ROWS; ++p) {
+            const char* src = reinterpret_cast<const char*>(c.lines + (uint64_t)slot[p] * CD);
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                if ((hitmask >> p) & 1)
+                    __builtin_amdgcn_global_load_lds((const void*)(src + (v * 64 + lane) * 16),
+                                                     (void __attribute__((address_space(3)))*)&stage[w][p][v * 64], 16, 0, NT ? 2 : 0);
+        }
+        id = id_next; id_next = id_next2;
+        ok = id < c.num_rows;
+        set = ok ? set_of(c, id) : 0;
+        kk = vu64x2{kEmptyKey, kEmptyKey};
+        if (ok) kk = *reinterpret_cast<const vu64x2*>(c.keys + set * COALA_WAYS + (lane & 15) * 2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // LDS-DMA landed (also the next tags)
+#pragma unroll
+        for (int p = 0; p < ROWS; ++p) {
+            vfloat4* dst = reinterpret_cast<vfloat4*>(out + (base + p) * (int64_t)c.dim);
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                if ((hitmask >> p) & 1) {
+                    const vfloat4 x = stage[w][p][v * 64 + lane];
+                    if (NT) __builtin_nontemporal_store(x, dst + v * 64 + lane);
+                    else dst[v * 64 + lane] = x;
+                }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // LDS reads done before the next chunk's DMA overwrites the slice
+    }
+}
+
 struct Variant {
     std::string name;
     std::function<void(hipStream_t)> launch;
@@ -149,6 +214,11 @@ int main(int argc, char** argv) {
                 vs.push_back({std::string(nm) + " g" + std::to_string(grid) + " b" + std::to_string(block),
                               [=](hipStream_t s) { hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, s, h->d, d_ids, out, n, 1u); }});
             };
+            for (int g : {1280, 2048, 2560}) {
+                add_v2("v3 lds-dma R4", probe_gather_lds<4, false>, g, 128);
+                add_v2("v3 lds-dma+nt R4", probe_gather_lds<4, true>, g, 128);
+                add_v2("v3 lds-dma+nt R2", probe_gather_lds<2, true>, g * 2, 128);
+            }
             for (auto gb : {std::pair<int, int>{512, 512}, {1024, 256}}) {
                 add_v2("v2 pipe  R4", probe_gather_v2<1024, false, 4>, gb.first, gb.second);
                 add_v2("v2 pipe+nt R4", probe_gather_v2<1024, true, 4>, gb.first, gb.second);

@@ -120,7 +120,7 @@ constexpr int kK1Waves = 2; // waves per block (measured: 2048 x 128 threads bea
 template <typename V> __device__ __forceinline__ V nt_load(const V* p) { return __builtin_nontemporal_load(p); }
 template <typename V> __device__ __forceinline__ void nt_store(V v, V* p) { __builtin_nontemporal_store(v, p); }
 
-template <int CD, int VEC, int NP = 4, bool FULL = false>
+template <int CD, int VEC, int NP = 4, bool FULL = false, bool NOMISS = false /* development only: tools/k1_bench */>
 __global__ __launch_bounds__(64 * kK1Waves, K1_MIN_WAVES) void probe_gather_kernel(CacheDev c, const int64_t* __restrict__ idx,
                                                                     float* __restrict__ out, int64_t n, uint32_t gen) {
     // FULL: dim == cache_dim, every lane of a row group moves data -> no per-lane bounds predicate around the row moves
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(64 * kK1Waves, K1_MIN_WAVES) void probe_gather_kern
             }
         }
         // ---- misses: push the row on its set's chain (the old head comes back behind the row loads)
-        const bool i_miss = lane < R && ((missmask >> lane) & 1);
+        const bool i_miss = !NOMISS && lane < R && ((missmask >> lane) & 1);
         unsigned long long prev = 0;
         if (i_miss) {
             const unsigned long long tag = ((unsigned long long)gen << 32) | (unsigned long long)(base + lane + 1);
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(64 * kK1Waves, K1_MIN_WAVES) void probe_gather_kern
         if (i_miss) {
             c.row_state[base + lane] = 1;
             c.miss_next[base + lane] = ((uint32_t)(prev >> 32) == gen) ? (uint32_t)prev : 0u;
-        } else if (lane < R && ((badmask >> lane) & 1)) {
+        } else if (!NOMISS && lane < R && ((badmask >> lane) & 1)) {
             c.row_state[base + lane] = 2;
         }
     }

@@ -284,6 +284,19 @@ def main():
     if world == 1 and args.mode == "minibatch" and args.epoch_steps > 0:
         epoch = run_epoch_leg(args, comm, graph, sampler, table, device, fanout, steps_per_epoch)
 
+    # the kernel that dominates the STEP TIME on this workload is the cold fill, bound by the host link, not by HBM
+    fill_launches = max(prof.fill_launches, 1)
+    fill_us = prof.fill_ms / fill_launches * 1e3
+    fill_bytes = prof.fill_rows * args.dim * 4 / fill_launches
+    pcie_peak = 63.0  # GB/s, PCIe Gen5 x16 spec (/opt/skills/guides/MI355X_MICROARCH.md "Host link")
+    roofline_cold = None
+    if args.cold_tier == "host" and prof.fill_rows:
+        ach = fill_bytes / (fill_us * 1e-6) / 1e9 if fill_us > 0 else 0.0
+        roofline_cold = {"bound": "pcie", "kernel": "miss_fill_kernel", "achieved": round(ach, 2), "peak": pcie_peak, "unit": "GB/s",
+                         "frac": round(ach / pcie_peak, 4), "avg_launch_us": round(fill_us, 2),
+                         "rows_per_launch": round(prof.fill_rows / fill_launches, 1), "alg_bytes_per_launch": int(fill_bytes),
+                         "note": "rows read zero-copy from pinned host memory; a pinned hipMemcpy H2D reaches 57.5 GB/s on this box"}
+
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and host_array is not None:
         cpu_baseline = run_cpu_baseline(args, host_array, batches[args.warmup:], fanout, graph, seeds_for)
@@ -305,6 +318,7 @@ def main():
                        "epoch_time_s_fetch_only_extrapolated": round(ms_per_step * steps_per_epoch / 1e3, 2)},
             "roofline": roofline,
             "roofline_allhit": roofline_allhit,
+            "roofline_cold_fill": roofline_cold,
             "epoch": epoch,
             "cpu_baseline": cpu_baseline,
         }

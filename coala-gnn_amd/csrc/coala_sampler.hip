@@ -44,67 +44,75 @@ __host__ __device__ inline uint64_t sample_key(uint64_t seed, uint64_t step, int
     return splitmix64(h ^ v);
 }
 
-// S1: one thread per destination node.
-__global__ __launch_bounds__(256) void sample_layer_kernel(const int64_t* __restrict__ indptr, const int64_t* __restrict__ indices,
-                                                           const int64_t* __restrict__ dst, const int64_t* __restrict__ n_dst_dev,
-                                                           int fanout, uint64_t seed, uint64_t step, int layer,
-                                                           int64_t num_nodes, int64_t* __restrict__ nbr) {
-    const int64_t n_dst = *n_dst_dev;
-    for (int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; d < n_dst; d += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t v = dst[d];
-        int64_t* row = nbr + d * fanout;
-        if (v < 0 || v >= num_nodes) {
-            for (int j = 0; j < fanout; ++j) row[j] = kEmpty;
-            continue;
-        }
-        const int64_t start = indptr[v];
-        const int64_t deg = indptr[v + 1] - start;
-        if (deg <= fanout) {
-            for (int j = 0; j < fanout; ++j) row[j] = (j < deg) ? indices[start + j] : kEmpty;
-            continue;
-        }
-        const uint64_t key = sample_key(seed, step, layer, (uint64_t)v);
-        int64_t chosen[32]; // fanout <= 32 (checked on the host)
-        int c = 0;
-        for (int64_t j = deg - fanout; j < deg; ++j) { // Floyd: a uniform fanout-subset of [0, deg)
-            const uint64_t r = splitmix64(key + (uint64_t)c);
-            int64_t t = (int64_t)__umul64hi(r, (uint64_t)(j + 1));
-            bool dup = false;
-            for (int q = 0; q < c; ++q) dup |= (chosen[q] == t);
-            if (dup) t = j;
-            chosen[c++] = t;
-        }
-        for (int j = 0; j < fanout; ++j) row[j] = indices[start + chosen[j]];
-    }
-}
-
 __device__ __forceinline__ uint32_t hash_slot(int64_t key, uint32_t mask) { return (uint32_t)splitmix64((uint64_t)key) & mask; }
 
 __device__ __forceinline__ int64_t item_key(const int64_t* dst, const int64_t* nbr, int64_t n_dst, int64_t p) {
     return p < n_dst ? dst[p] : nbr[p - n_dst];
 }
 
-// S2: insert every item (dst nodes, then sampled neighbours) and keep the smallest position per key.
-__global__ __launch_bounds__(256) void hash_insert_kernel(const int64_t* __restrict__ dst, const int64_t* __restrict__ nbr,
-                                                          const int64_t* __restrict__ n_dst_dev, int fanout, long long* __restrict__ keys,
-                                                          uint32_t* __restrict__ minpos, uint32_t mask, uint32_t* __restrict__ slot_of_item) {
+// S1+S2 fused, a lane per sampled neighbour: GS lanes (16/32/64 >= fanout+1) work on one destination node.  Lane c < fanout
+// draws Floyd's c-th candidate on its own, the duplicate resolution walks c = 0..fanout-1 with one shuffle + one ballot per
+// step (bit-identical to the sequential loop of the CPU twin), then every lane loads ITS neighbour and inserts it into the
+// hash table; lane `fanout` inserts the destination node itself.  Replaces the thread-per-node sampler followed by a separate
+// insert kernel: the index loads and the CAS chains of one node now run side by side instead of one after the other.
+template <int GS>
+__global__ __launch_bounds__(256) void sample_insert_kernel(const int64_t* __restrict__ indptr, const int64_t* __restrict__ indices,
+                                                            const int64_t* __restrict__ dst, const int64_t* __restrict__ n_dst_dev,
+                                                            int fanout, uint64_t seed, uint64_t step, int layer, int64_t num_nodes,
+                                                            int64_t* __restrict__ nbr, long long* __restrict__ keys,
+                                                            uint32_t* __restrict__ minpos, uint32_t mask, uint32_t* __restrict__ slot_of_item) {
+    constexpr int GPW = 64 / GS; // groups per wave
     const int64_t n_dst = *n_dst_dev;
-    const int64_t n_items = n_dst * (fanout + 1);
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_items; p += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t k = item_key(dst, nbr, n_dst, p);
-        if (k < 0) { slot_of_item[p] = 0xFFFFFFFFu; continue; }
-        uint32_t s = hash_slot(k, mask);
-        while (true) {
-            const long long cur = keys[s];
-            if (cur == k) break;
-            if (cur == kEmpty) {
-                const long long old = atomicCAS((unsigned long long*)(keys + s), (unsigned long long)kEmpty, (unsigned long long)k);
-                if (old == kEmpty || old == k) break;
-            }
-            s = (s + 1) & mask;
+    const int lane = threadIdx.x & 63;
+    const int gl = lane % GS;
+    const int gbase = lane - gl;
+    const uint64_t gmask = (GS == 64) ? ~0ull : (((1ull << GS) - 1ull) << gbase);
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t d0 = wave * GPW; d0 < n_dst; d0 += n_waves * GPW) { // wave-uniform trip count: ballots below need every lane
+        const int64_t d = d0 + lane / GS;
+        const bool active = d < n_dst;
+        const int64_t v = active ? dst[d] : -1;
+        const bool okv = active && v >= 0 && v < num_nodes;
+        const int64_t start = okv ? indptr[v] : 0;
+        const int64_t deg = okv ? indptr[v + 1] - start : 0;
+        // candidate of lane c = gl (Floyd step j = deg - fanout + c)
+        const uint64_t key = sample_key(seed, step, layer, (uint64_t)v);
+        const int64_t jmine = deg - fanout + gl;
+        const int64_t t = (deg > fanout && gl < fanout) ? (int64_t)__umul64hi(splitmix64(key + (uint64_t)gl), (uint64_t)(jmine + 1)) : -1;
+        int64_t chosen = -2;
+        for (int c = 0; c < fanout; ++c) {
+            const int64_t tc = __shfl(t, gbase + c);
+            const uint64_t dupm = __ballot(gl < c && chosen == tc) & gmask;
+            if (gl == c) chosen = dupm ? (deg - fanout + c) : tc;
         }
-        atomicMin(minpos + s, (uint32_t)p);
-        slot_of_item[p] = s;
+        int64_t pick = -1;
+        if (gl < fanout) pick = (deg <= fanout) ? (gl < deg ? (int64_t)gl : -1) : chosen;
+        const int64_t nb = (okv && pick >= 0) ? indices[start + pick] : kEmpty;
+        if (active && gl < fanout) nbr[d * fanout + gl] = nb;
+        // ---- hash insert: neighbours at positions n_dst + d*fanout + gl, the node itself at position d
+        int64_t k = kEmpty;
+        int64_t p = -1;
+        if (active && gl < fanout) { k = nb; p = n_dst + d * fanout + gl; }
+        else if (active && gl == fanout) { k = v; p = d; }
+        if (p >= 0) {
+            if (k < 0) {
+                slot_of_item[p] = 0xFFFFFFFFu;
+            } else {
+                uint32_t s = hash_slot(k, mask);
+                while (true) {
+                    const long long cur = keys[s];
+                    if (cur == k) break;
+                    if (cur == kEmpty) {
+                        const long long old = atomicCAS((unsigned long long*)(keys + s), (unsigned long long)kEmpty, (unsigned long long)k);
+                        if (old == kEmpty || old == k) break;
+                    }
+                    s = (s + 1) & mask;
+                }
+                atomicMin(minpos + s, (uint32_t)p);
+                slot_of_item[p] = s;
+            }
+        }
     }
 }
 
@@ -386,10 +394,15 @@ int coala_sampler_sample(coala_sampler_t* s, const int64_t* seeds, int64_t n_see
         long long* keys = s->keys;
         uint32_t* minpos = reinterpret_cast<uint32_t*>(s->keys + tbl);
         HIPCHK(hipMemsetAsync(keys, 0xFF, tbl * (sizeof(long long) + sizeof(uint32_t)), st));
-        hipLaunchKernelGGL(sample_layer_kernel, dim3(grid1d(cap, 256, 4096)), dim3(256), 0, st, s->indptr, s->indices, dst, n_dst_dev, f,
-                           seed, step, l, s->num_nodes, s->nbr_global);
-        hipLaunchKernelGGL(hash_insert_kernel, dim3(grid1d(items_cap, 256, 8192)), dim3(256), 0, st, dst, s->nbr_global, n_dst_dev, f,
-                           keys, minpos, mask, s->slot_of_item);
+        if (f < 16)
+            hipLaunchKernelGGL(sample_insert_kernel<16>, dim3(grid1d(cap * 16, 256, 8192)), dim3(256), 0, st, s->indptr, s->indices, dst,
+                               n_dst_dev, f, seed, step, l, s->num_nodes, s->nbr_global, keys, minpos, mask, s->slot_of_item);
+        else if (f < 32)
+            hipLaunchKernelGGL(sample_insert_kernel<32>, dim3(grid1d(cap * 32, 256, 8192)), dim3(256), 0, st, s->indptr, s->indices, dst,
+                               n_dst_dev, f, seed, step, l, s->num_nodes, s->nbr_global, keys, minpos, mask, s->slot_of_item);
+        else
+            hipLaunchKernelGGL(sample_insert_kernel<64>, dim3(grid1d(cap * 64, 256, 8192)), dim3(256), 0, st, s->indptr, s->indices, dst,
+                               n_dst_dev, f, seed, step, l, s->num_nodes, s->nbr_global, keys, minpos, mask, s->slot_of_item);
         if (items_cap <= kSmallItems) {
             hipLaunchKernelGGL(flag_scan_assign_small_kernel, dim3(1), dim3(1024), 0, st, dst, s->nbr_global, n_dst_dev, f, s->slot_of_item,
                                minpos, s->local_of_slot, src_nodes_out[l], s->counts_dev + l + 1);

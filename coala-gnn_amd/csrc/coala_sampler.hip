@@ -294,6 +294,9 @@ struct coala_sampler {
     uint32_t* slot_of_item = nullptr; uint64_t item_cap = 0;
     uint32_t* tile_sums = nullptr;    uint64_t tile_cap = 0;
     int64_t* counts_dev = nullptr;    // [kMaxLayers+1] dst/src counts per layer
+    int64_t* counts_pinned = nullptr; // pinned host staging for the seed count (H2D) and the per-layer source counts (D2H):
+                                      // a ring of 8 slots so that asynchronous calls (n_src_host == NULL) do not overwrite each other
+    uint64_t calls = 0;
 };
 
 extern "C" {
@@ -309,7 +312,8 @@ int coala_sampler_create(int device, const int64_t* indptr, const int64_t* indic
     s->indices = indices;
     s->num_nodes = num_nodes;
     s->num_edges = num_edges;
-    if (hipMalloc((void**)&s->counts_dev, (COALA_SAMPLER_MAX_LAYERS + 1) * sizeof(int64_t)) != hipSuccess) {
+    if (hipMalloc((void**)&s->counts_dev, (COALA_SAMPLER_MAX_LAYERS + 1) * sizeof(int64_t)) != hipSuccess ||
+        hipHostMalloc((void**)&s->counts_pinned, 8 * (COALA_SAMPLER_MAX_LAYERS + 2) * sizeof(int64_t)) != hipSuccess) {
         delete s;
         return fail(COALA_ENOMEM, "hipMalloc failed");
     }
@@ -324,6 +328,7 @@ int coala_sampler_destroy(coala_sampler_t* s) {
     void* ptrs[] = {s->nbr_global, s->keys, s->minpos, s->local_of_slot, s->slot_of_item, s->tile_sums, s->counts_dev};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    if (s->counts_pinned) (void)hipHostFree(s->counts_pinned);
     delete s;
     return COALA_OK;
 }
@@ -379,8 +384,9 @@ int coala_sampler_sample(coala_sampler_t* s, const int64_t* seeds, int64_t n_see
             if (n_src_host) n_src_host[l] = 0;
         return COALA_OK;
     }
-    const int64_t n0 = n_seeds;
-    HIPCHK(hipMemcpyAsync(s->counts_dev, &n0, sizeof(int64_t), hipMemcpyHostToDevice, st));
+    int64_t* pin = s->counts_pinned + (s->calls++ % 8) * (COALA_SAMPLER_MAX_LAYERS + 2);
+    pin[0] = n_seeds; // pinned: a truly asynchronous 8-byte H2D (a pageable source is staged synchronously)
+    HIPCHK(hipMemcpyAsync(s->counts_dev, pin, sizeof(int64_t), hipMemcpyHostToDevice, st));
     const int64_t* dst = seeds;
     cap = n_seeds;
     for (int l = 0; l < n_layers; ++l) {
@@ -420,8 +426,9 @@ int coala_sampler_sample(coala_sampler_t* s, const int64_t* seeds, int64_t n_see
     }
     HIPCHK(hipGetLastError());
     if (n_src_host) { // the one host read of the call: every layer's source count
-        HIPCHK(hipMemcpyAsync(n_src_host, s->counts_dev + 1, n_layers * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(pin + 1, s->counts_dev + 1, n_layers * sizeof(int64_t), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
+        for (int l = 0; l < n_layers; ++l) n_src_host[l] = pin[1 + l];
     }
     return COALA_OK;
 }

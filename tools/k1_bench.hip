@@ -208,7 +208,7 @@ int main(int argc, char** argv) {
             else if (dim == 128 && np == 2) hipLaunchKernelGGL((probe_gather_kernel<128, 4, 2>), dim3(grid), dim3(block), 0, s, h->d, d_ids, out, n, fake_gen);
         }});
     };
-    add_prod(2048, 128, 4); add_prod(2048, 128, 5); add_prod(2048, 128, 6); add_prod(2560, 128, 6);
+    add_prod(2048, 128, 5); add_prod(1536, 128, 5); add_prod(2304, 128, 5); add_prod(1152, 256, 5); add_prod(3072, 64, 5); add_prod(4608, 64, 5); add_prod(2560, 128, 5);
     if (hit_pct == 100) {
         if (dim == 1024) {
             auto add_v2 = [&](const char* nm, auto kern, int grid, int block) {

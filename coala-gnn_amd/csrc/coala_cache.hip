@@ -531,6 +531,10 @@ struct coala_cache {
     std::vector<hipEvent_t> ev_pool;
     coala_cache_profile_t prof{};
     uint64_t table_bytes = 0;
+    int k2_grid_cap = kStatBlocks;        // K2 blocks: 64 when the cold tier is host memory.  The link, not the chip, is the limit: 256
+                                          // waves keep ~3 MB of PCIe reads in flight, a full grid only parks waves on every CU.
+                                          // Measured (default bench): 2048 / 512 / 128 / 64 / 16 / 8 blocks -> 53.7 / 53.7 / 56.2 /
+                                          // 56.6 / 55.8 / 43.1 GB/s, and the prefetching epoch step 2.25 -> 2.00 ms.  COALA_K2_GRID
     int k1_passes = 4;                    // rows(-pairs) in flight per wave in K1 (tunable: COALA_K1_PASSES = 2 | 4)
     int k1_grid_cap = 256 * 8;            // K1 blocks (tunable: COALA_K1_GRID)
     uint64_t rows_total = 0;              // rows submitted since the last stats reset (hits = rows - misses - rejected)
@@ -724,6 +728,13 @@ int coala_cache_create(const coala_cache_config_t* cfg, coala_cache_t** out) {
         h->gen = 0;
         if (const char* e = getenv("COALA_K1_PASSES")) h->k1_passes = atoi(e) == 2 ? 2 : 4;
         if (const char* e = getenv("COALA_K1_GRID")) { int g = atoi(e); if (g >= 1 && g <= 65535) h->k1_grid_cap = g; }
+        {
+            hipPointerAttribute_t attr;
+            const bool host_tier = hipPointerGetAttributes(&attr, cfg->cold_table) == hipSuccess && attr.type == hipMemoryTypeHost;
+            (void)hipGetLastError(); // an unregistered pointer is reported as an error: not ours to keep
+            h->k2_grid_cap = host_tier ? 64 : kStatBlocks;
+            if (const char* e = getenv("COALA_K2_GRID")) { int g = atoi(e); if (g >= 1 && g <= kStatBlocks) h->k2_grid_cap = g; }
+        }
         if (cfg->max_batch) rc = ensure_scratch(h, cfg->max_batch, nullptr);
     } while (0);
     if (rc == COALA_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(COALA_EHIP, "device sync failed after create");
@@ -804,7 +815,7 @@ static int read_feature_impl(coala_cache_t* h, float* out, const int64_t* idx, i
         }
         {
             ProfScope ps(h, s, 2, 0);
-            hipLaunchKernelGGL((miss_fill_kernel<CD, VEC>), dim3(grid_for(chunks, 4, kStatBlocks)), dim3(256), 0, s, d, idx, out, n);
+            hipLaunchKernelGGL((miss_fill_kernel<CD, VEC>), dim3(grid_for(chunks, 4, h->k2_grid_cap)), dim3(256), 0, s, d, idx, out, n);
         }
         h->rows_total += (uint64_t)n;
         return COALA_OK;

@@ -113,6 +113,7 @@ class COALA_GNN_DataLoader(torch.utils.data.DataLoader):
         self._producer = None
         self._queue = None
         self._side_stream = None
+        self._sample_stream = None
         self.refresh_counter = refresh_counter
         self.sampler = graph_sampler
         self.batch_size = batch_size
@@ -159,14 +160,37 @@ class COALA_GNN_DataLoader(torch.utils.data.DataLoader):
         self.counter = 0
 
     def _producer_loop(self):
+        """Two stages on two HIP streams: the sampler of step t+1 runs (and its count read-back blocks this thread) while the
+        fetch of step t -- enqueued without a host wait -- is still pulling rows over PCIe."""
         try:
             torch.cuda.set_device(self.device)
-            with torch.cuda.stream(self._side_stream):
-                while self.counter < self.total_count:
-                    item = self._produce_one()
+            mgr = self.COALA_GNN_Manager
+            keep_sync = mgr.sync_on_return
+            mgr.sync_on_return = False  # the consumer waits on an event instead
+
+            def sample_next():
+                is_last_iter = self.counter + 1 >= self.total_count
+                seeds = self.scheduler.run(is_last_iter)
+                with torch.cuda.stream(self._sample_stream):
+                    batch = self.sampler.sample(self.g, seeds.to(self.device))
                     ev = torch.cuda.Event()
-                    ev.record(self._side_stream)
-                    self._queue.put((item, ev))
+                    ev.record(self._sample_stream)
+                self.counter += 1
+                return batch, ev
+
+            nxt = sample_next() if self.counter < self.total_count else None
+            while nxt is not None:
+                batch, ev_s = nxt
+                with torch.cuda.stream(self._side_stream):
+                    self._side_stream.wait_event(ev_s)
+                    for t in _device_tensors(batch):
+                        t.record_stream(self._side_stream)  # allocated on the sampler's stream, read by the fetch kernels
+                    item = mgr.fetch_feature(batch)
+                    ev_f = torch.cuda.Event()
+                    ev_f.record(self._side_stream)
+                nxt = sample_next() if self.counter < self.total_count else None  # overlaps the fetch just enqueued
+                self._queue.put((item, ev_f))
+            mgr.sync_on_return = keep_sync
             self._queue.put(None)
         except BaseException as e:  # surface producer failures in the consumer
             self._queue.put(e)
@@ -183,6 +207,7 @@ class COALA_GNN_DataLoader(torch.utils.data.DataLoader):
             self._queue = queue.Queue(maxsize=self.prefetch)
             if self._side_stream is None:
                 self._side_stream = torch.cuda.Stream(device=self.device)
+                self._sample_stream = torch.cuda.Stream(device=self.device)
             self._producer = threading.Thread(target=self._producer_loop, daemon=True)
             self._producer.start()
         got = self._queue.get()

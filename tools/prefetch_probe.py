@@ -1,0 +1,42 @@
+import os, sys, time, tempfile
+ROOT = "/root/repo"
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "coala-gnn_amd"))
+import numpy as np, torch
+from COALA_GNN import MPI_Comm_Manager, Node_Distributor, SSD_INFO, COALA_GNN_DataLoader
+from COALA_GNN.harness import SageMean
+from COALA_GNN.sampler import NeighborSampler
+from COALA_GNN.synthetic import alloc_pinned_table, block_colors, powerlaw_csc
+import COALA_GNN.COALA_GNN_DataLoader as DL
+import sys as _s
+_s.setswitchinterval(float(os.environ.get("SWITCH", "0.005")))
+rows, dim, batch, fan = 10_000_000, 1024, 1024, [5, 5]
+torch.cuda.set_device(0)
+table = alloc_pinned_table(rows, dim, 0, 0)
+indptr, indices = powerlaw_csc(rows, 12.0, seed=0, device="cuda")
+comm = MPI_Comm_Manager(0); comm.initialize_nested_process_group("isolated")
+tmp = tempfile.mkdtemp()
+color, tk, sc, _ = block_colors(rows)
+files = [os.path.join(tmp, f) for f in ("color.npy", "topk.npy", "score.npy")]
+np.save(files[0], color); np.save(files[1], tk); np.save(files[2], sc)
+ids = torch.randperm(int(0.6 * rows), generator=torch.Generator().manual_seed(0))[: 1200 * batch]
+sampler = NeighborSampler(fan, seed=0)
+g = sampler.make_graph(indptr, indices, ndata={"labels": (torch.arange(rows, device="cuda") * 7) % 19})
+for train in (False, True):
+    nd = Node_Distributor(comm, ids, batch, *files, parsing_method="baseline")
+    loader = COALA_GNN_DataLoader(SSD_INFO(1, 4096, 1024, 0), nd, g, sampler, batch, dim, fan, 4096, "cuda:0", cache_backend="isolated", sim_buf=table, num_rows=rows, prefetch=2)
+    model = SageMean(dim, 128, 19).cuda(); opt = torch.optim.Adam(model.parameters(), 1e-3); lossf = torch.nn.CrossEntropyLoss()
+    n = 0; wait = 0.0; t_train = 0.0
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    it = iter(loader)
+    while True:
+        a = time.perf_counter()
+        try: inp, sd, blocks, feat = next(it)
+        except StopIteration: break
+        b = time.perf_counter(); wait += b - a
+        if train:
+            loss = lossf(model(blocks, feat), blocks[-1].dstdata["labels"].view(-1)); opt.zero_grad(); loss.backward(); opt.step()
+        t_train += time.perf_counter() - b
+        n += 1
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print(f"train={train}: {n} steps, {dt/n*1e3:.3f} ms/step, consumer wait {wait/n*1e3:.3f} ms/step, consumer python in train {t_train/n*1e3:.3f} ms/step")
+    del loader, nd

@@ -247,7 +247,8 @@ def main():
     roofline = {
         "bound": "hbm", "kernel": "probe_gather_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": _pmc_traffic(args, world),
-        "avg_launch_us": round(k_ms * 1e3, 2), "launches": int(prof.gather_launches),
+        "avg_launch_us": round(k_ms * 1e3, 2), "event_bracket_overhead_us": round(prof.event_overhead_us, 2),
+        "launches": int(prof.gather_launches),
         "rows_per_launch": round(prof.gather_rows / launches, 1), "hits_per_launch": round(prof.gather_hits / launches, 1),
         "alg_bytes_per_launch": int(alg_bytes / launches),
         "cold_fill_avg_us": round(prof.fill_ms / max(prof.fill_launches, 1) * 1e3, 2),

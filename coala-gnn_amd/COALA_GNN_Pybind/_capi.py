@@ -29,7 +29,7 @@ class CacheGeometry(C.Structure):
 class CacheProfile(C.Structure):
     _fields_ = [("gather_ms", C.c_double), ("gather_launches", C.c_uint64), ("gather_rows", C.c_uint64),
                 ("gather_hits", C.c_uint64), ("fill_ms", C.c_double), ("fill_launches", C.c_uint64),
-                ("fill_rows", C.c_uint64), ("rank_ms", C.c_double)]
+                ("fill_rows", C.c_uint64), ("rank_ms", C.c_double), ("event_overhead_us", C.c_double)]
 
 
 # every exported symbol of include/coala_hip.h: name -> (restype, argtypes)

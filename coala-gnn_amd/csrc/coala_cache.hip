@@ -21,6 +21,7 @@
 //                     host over PCIe, or HBM) into the output.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -530,6 +531,7 @@ struct coala_cache {
     std::vector<EvPair> ev_live;
     std::vector<hipEvent_t> ev_pool;
     coala_cache_profile_t prof{};
+    hipStream_t last_stream = nullptr;    // stream of the last bracketed launch (for the empty-bracket calibration)
     uint64_t table_bytes = 0;
     int k2_grid_cap = kStatBlocks;        // K2 blocks: 64 when the cold tier is host memory.  The link, not the chip, is the limit: 256
                                           // waves keep ~3 MB of PCIe reads in flight, a full grid only parks waves on every CU.
@@ -603,7 +605,7 @@ struct ProfScope {
             if (h->ev_live.size() >= 8192) drain_events(h);
             a = take_event(h); b = take_event(h);
             on = a && b;
-            if (on) (void)hipEventRecord(a, s);
+            if (on) { (void)hipEventRecord(a, s); h->last_stream = s; }
         }
     }
     ~ProfScope() {
@@ -949,6 +951,23 @@ int coala_cache_profile(coala_cache_t* h, coala_cache_profile_t* out, int reset)
     const uint64_t th = h->cum_hit + v0, tm = h->cum_miss + v1;
     h->prof.gather_hits = th - h->prof_hit0;
     h->prof.fill_rows = tm - h->prof_miss0;
+    if (h->cfg.flags & COALA_FLAG_PROFILE) { // empty brackets on the same stream: the cost of the measurement itself
+        std::vector<float> gaps;
+        for (int i = 0; i < 16; ++i) {
+            hipEvent_t a = take_event(h), b = take_event(h);
+            if (!a || !b) break;
+            float ms = 0.f;
+            if (hipEventRecord(a, h->last_stream) == hipSuccess && hipEventRecord(b, h->last_stream) == hipSuccess &&
+                hipEventSynchronize(b) == hipSuccess && hipEventElapsedTime(&ms, a, b) == hipSuccess)
+                gaps.push_back(ms);
+            h->ev_pool.push_back(a);
+            h->ev_pool.push_back(b);
+        }
+        if (!gaps.empty()) {
+            std::sort(gaps.begin(), gaps.end());
+            h->prof.event_overhead_us = gaps[gaps.size() / 2] * 1e3;
+        }
+    }
     *out = h->prof;
     if (reset) { h->prof = coala_cache_profile_t{}; h->prof_hit0 = th; h->prof_miss0 = tm; }
     return COALA_OK;

@@ -160,7 +160,9 @@ typedef struct coala_cache_profile {
     double fill_ms;
     uint64_t fill_launches;
     uint64_t fill_rows;
-    double rank_ms;
+    double rank_ms;          /* unused since the rank step was fused into the fill kernel (always 0) */
+    double event_overhead_us; /* median elapsed time of an EMPTY hipEvent bracket on the same stream: what every bracketed */
+                              /* launch above includes on top of the kernel itself                                        */
 } coala_cache_profile_t;
 int coala_cache_profile(coala_cache_t* h, coala_cache_profile_t* out, int reset);
 

@@ -16,7 +16,7 @@
 namespace {
 
 // ---------------------------------------------------------------- experimental variant: software-pipelined, optional nt
-template <int CD, bool NT, int PASSES_>
+template <int CD, bool NT, int PASSES_, int EXTRA = 0 /* 1: valid/ok/bad ballots + bad zero rows  2: + miss push and row_state */>
 __global__ __launch_bounds__(1024) void probe_gather_v2(CacheDev c, const int64_t* __restrict__ idx, float* __restrict__ out,
                                                         int64_t n, uint32_t gen) {
     // all-hit fast path only (no miss bookkeeping): measures what the data movement alone can reach
@@ -44,15 +44,28 @@ __global__ __launch_bounds__(1024) void probe_gather_v2(CacheDev c, const int64_
         const int64_t base = chunk * R;
         const uint64_t m0 = __ballot(ok && kk.x == id);
         const uint64_t m1 = __ballot(ok && kk.y == id);
+        const uint64_t okm = EXTRA ? __ballot(ok) : 0;
+        const uint64_t vm = EXTRA ? __ballot(id != 0xFFFFFFFFFFFFFFFFull) : 0;
         uint32_t slot[R];
-        uint32_t hitmask = 0;
+        uint32_t hitmask = 0, missmask = 0, badmask = 0;
+        uint64_t my_set = 0;
 #pragma unroll
         for (int q = 0; q < R; ++q) {
             const uint32_t a = (uint32_t)(m0 >> (16 * q)) & 0xFFFFu, b = (uint32_t)(m1 >> (16 * q)) & 0xFFFFu, mm = a | b;
             const uint64_t set_q = readlane64(set, 16 * q);
             uint32_t way = 0;
             if (mm) { const int j = __builtin_ctz(mm); way = 2 * j + (((a >> j) & 1) ? 0 : 1); hitmask |= 1u << q; }
+            else if (EXTRA && ((okm >> (16 * q)) & 1)) missmask |= 1u << q;
+            else if (EXTRA && ((vm >> (16 * q)) & 1)) badmask |= 1u << q;
             slot[q] = (uint32_t)(set_q * COALA_WAYS) + way;
+            if (EXTRA >= 2 && lane == q) my_set = set_q;
+        }
+        const bool i_miss = EXTRA >= 2 && lane < R && ((missmask >> lane) & 1);
+        unsigned long long prev = 0;
+        if (i_miss) {
+            const unsigned long long tag = ((unsigned long long)gen << 32) | (unsigned long long)(base + lane + 1);
+            prev = atomicExch(reinterpret_cast<unsigned long long*>(c.set_head + my_set), tag);
+            atomicAdd(c.set_cnt + my_set, 1u);
         }
         // id two chunks ahead
         const int64_t ch2 = chunk + 2 * n_waves;
@@ -80,7 +93,13 @@ __global__ __launch_bounds__(1024) void probe_gather_v2(CacheDev c, const int64_
                 if ((hitmask >> p) & 1) {
                     if (NT) __builtin_nontemporal_store(val[p][v], dst + v * 64 + lane);
                     else dst[v * 64 + lane] = val[p][v];
-                }
+                } else if (EXTRA && ((badmask >> p) & 1)) dst[v * 64 + lane] = V(0.0f);
+        }
+        if (EXTRA >= 2) {
+            if (i_miss) {
+                c.row_state[base + lane] = 1;
+                c.miss_next[base + lane] = ((uint32_t)(prev >> 32) == gen) ? (uint32_t)prev : 0u;
+            } else if (lane < R && ((badmask >> lane) & 1)) c.row_state[base + lane] = 2;
         }
     }
 }
@@ -201,6 +220,7 @@ int main(int argc, char** argv) {
             ++fake_gen;
             if (dim == 1024 && np == 4) hipLaunchKernelGGL((probe_gather_kernel<1024, 4, 4, false>), dim3(grid), dim3(block), 0, s, h->d, d_ids, out, n, fake_gen);
             else if (dim == 1024 && np == 6) hipLaunchKernelGGL((probe_gather_kernel<1024, 4, 4, true, true>), dim3(grid), dim3(block), 0, s, h->d, d_ids, out, n, fake_gen);
+            else if (dim == 1024 && np == 7) hipLaunchKernelGGL((probe_gather_kernel<1024, 4, 4, true, false, false>), dim3(grid), dim3(block), 0, s, h->d, d_ids, out, n, fake_gen);
             else if (dim == 1024 && np == 5) hipLaunchKernelGGL((probe_gather_kernel<1024, 4, 4, true>), dim3(grid), dim3(block), 0, s, h->d, d_ids, out, n, fake_gen);
             else if (dim == 128 && np == 5) hipLaunchKernelGGL((probe_gather_kernel<128, 4, 4, true>), dim3(grid), dim3(block), 0, s, h->d, d_ids, out, n, fake_gen);
             else if (dim == 1024 && np == 2) hipLaunchKernelGGL((probe_gather_kernel<1024, 4, 2>), dim3(grid), dim3(block), 0, s, h->d, d_ids, out, n, fake_gen);
@@ -208,23 +228,20 @@ int main(int argc, char** argv) {
             else if (dim == 128 && np == 2) hipLaunchKernelGGL((probe_gather_kernel<128, 4, 2>), dim3(grid), dim3(block), 0, s, h->d, d_ids, out, n, fake_gen);
         }});
     };
-    add_prod(2048, 128, 5); add_prod(1536, 128, 5); add_prod(2304, 128, 5); add_prod(1152, 256, 5); add_prod(3072, 64, 5); add_prod(4608, 64, 5); add_prod(2560, 128, 5);
+    add_prod(2048, 128, 5); add_prod(2048, 128, 7); add_prod(2048, 128, 5); add_prod(2048, 128, 7);
     if (hit_pct == 100) {
         if (dim == 1024) {
             auto add_v2 = [&](const char* nm, auto kern, int grid, int block) {
                 vs.push_back({std::string(nm) + " g" + std::to_string(grid) + " b" + std::to_string(block),
                               [=](hipStream_t s) { hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, s, h->d, d_ids, out, n, 1u); }});
             };
-            for (int g : {1280, 2048, 2560}) {
-                add_v2("v3 lds-dma R4", probe_gather_lds<4, false>, g, 128);
+            for (int g : {2048}) {
                 add_v2("v3 lds-dma+nt R4", probe_gather_lds<4, true>, g, 128);
-                add_v2("v3 lds-dma+nt R2", probe_gather_lds<2, true>, g * 2, 128);
             }
-            for (auto gb : {std::pair<int, int>{512, 512}, {1024, 256}}) {
-                add_v2("v2 pipe  R4", probe_gather_v2<1024, false, 4>, gb.first, gb.second);
+            for (auto gb : {std::pair<int, int>{2048, 128}}) {
                 add_v2("v2 pipe+nt R4", probe_gather_v2<1024, true, 4>, gb.first, gb.second);
-                add_v2("v2 pipe  R2", probe_gather_v2<1024, false, 2>, gb.first * 2, gb.second);
-                add_v2("v2 pipe+nt R2", probe_gather_v2<1024, true, 2>, gb.first * 2, gb.second);
+                add_v2("v2+classify", probe_gather_v2<1024, true, 4, 1>, gb.first, gb.second);
+                add_v2("v2+classify+miss", probe_gather_v2<1024, true, 4, 2>, gb.first, gb.second);
             }
         }
     }

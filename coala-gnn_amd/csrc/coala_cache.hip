@@ -121,8 +121,7 @@ constexpr int kK1Waves = 2; // waves per block (measured: 2048 x 128 threads bea
 template <typename V> __device__ __forceinline__ V nt_load(const V* p) { return __builtin_nontemporal_load(p); }
 template <typename V> __device__ __forceinline__ void nt_store(V v, V* p) { __builtin_nontemporal_store(v, p); }
 
-template <int CD, int VEC, int NP = 4, bool FULL = false, bool NOMISS = false /* development only: tools/k1_bench */,
-          bool UNCOND = false /* predicate-free fast path for all-hit chunks: measured SLOWER (55 vs 49 us all-hit), kept for A/B */>
+template <int CD, int VEC, int NP = 4, bool FULL = false, bool NOMISS = false /* development only: tools/k1_bench */>
 __global__ __launch_bounds__(64 * kK1Waves, K1_MIN_WAVES) void probe_gather_kernel(CacheDev c, const int64_t* __restrict__ idx,
                                                                     float* __restrict__ out, int64_t n, uint32_t gen) {
     // FULL: dim == cache_dim, every lane of a row group moves data -> no per-lane bounds predicate around the row moves
@@ -219,66 +218,37 @@ __global__ __launch_bounds__(64 * kK1Waves, K1_MIN_WAVES) void probe_gather_kern
         const Ids ids_next2 = load_ids(chunk + 2 * n_waves);
 
         // ---- hits: HBM line -> registers -> output row, PASSES row(-pair)s in flight, next chunk's tags requested in between.
-        // Two code paths, chosen per chunk (wave-uniform):
-        //  * every row of the chunk hits (the common case once the cache is warm): loads and stores without any predicate, so
-        //    the compiler's scoreboard is exact and each store waits only for ITS load (counted vmcnt).  With the loads inside
-        //    conditional blocks it falls back to s_waitcnt vmcnt(0) between the stores, which serialises them (seen in the ISA);
-        //  * mixed chunk: predicated loads/stores (a dummy-address variant of the first path costs 2 us at 10 % hits).
+        // (Measured alternatives that did not pay: unconditional loads through a dummy address so that the stores get counted
+        // vmcnt(N) waits, and a predicate-free second path for all-hit chunks: DESIGN.md section 4.)
         const int sub = (G::RPP == 2) ? (lane >> 5) : 0;
         const int l_in = lane & (G::LPR - 1);
-        constexpr uint32_t kAllRows = (R >= 32) ? 0xFFFFFFFFu : ((1u << R) - 1u);
         V val[G::PASSES][G::VPL];
-        if (UNCOND && hitmask == kAllRows) {
 #pragma unroll
-            for (int p = 0; p < G::PASSES; ++p) {
-                const uint32_t s = (G::RPP == 2) ? (sub ? slot[p * G::RPP + (G::RPP - 1)] : slot[p * G::RPP]) : slot[p];
-                const V* src = reinterpret_cast<const V*>(c.lines + (uint64_t)s * CD);
+        for (int p = 0; p < G::PASSES; ++p) {
+            const int q = p * G::RPP + sub;
+            const uint32_t s = (G::RPP == 2) ? (sub ? slot[p * G::RPP + (G::RPP - 1)] : slot[p * G::RPP]) : slot[p];
+            const bool h = (hitmask >> q) & 1;
+            const V* src = reinterpret_cast<const V*>(c.lines + (uint64_t)s * CD);
 #pragma unroll
-                for (int v = 0; v < G::VPL; ++v) {
-                    const uint32_t u = v * G::LPR + l_in;
-                    val[p][v] = nt_load(src + ((FULL || u < nunits) ? u : 0u)); // lanes past dim re-read word 0 of the line
-                }
+            for (int v = 0; v < G::VPL; ++v) {
+                const uint32_t u = v * G::LPR + l_in;
+                if (h && (FULL || u < nunits)) val[p][v] = nt_load(src + u);
             }
-            tags = load_tags(ids_next);
-            ids_next = ids_next2;
+        }
+        tags = load_tags(ids_next);
+        ids_next = ids_next2;
 #pragma unroll
-            for (int p = 0; p < G::PASSES; ++p) {
-                const int q = p * G::RPP + sub;
-                V* dst = reinterpret_cast<V*>(out + (base + q) * (int64_t)c.dim);
+        for (int p = 0; p < G::PASSES; ++p) {
+            const int q = p * G::RPP + sub;
+            const bool h = (hitmask >> q) & 1;
+            const bool bad = (badmask >> q) & 1;
+            V* dst = reinterpret_cast<V*>(out + (base + q) * (int64_t)c.dim);
 #pragma unroll
-                for (int v = 0; v < G::VPL; ++v) {
-                    const uint32_t u = v * G::LPR + l_in;
-                    if (FULL || u < nunits) nt_store(val[p][v], dst + u);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int p = 0; p < G::PASSES; ++p) {
-                const int q = p * G::RPP + sub;
-                const uint32_t s = (G::RPP == 2) ? (sub ? slot[p * G::RPP + (G::RPP - 1)] : slot[p * G::RPP]) : slot[p];
-                const bool h = (hitmask >> q) & 1;
-                const V* src = reinterpret_cast<const V*>(c.lines + (uint64_t)s * CD);
-#pragma unroll
-                for (int v = 0; v < G::VPL; ++v) {
-                    const uint32_t u = v * G::LPR + l_in;
-                    if (h && (FULL || u < nunits)) val[p][v] = nt_load(src + u);
-                }
-            }
-            tags = load_tags(ids_next);
-            ids_next = ids_next2;
-#pragma unroll
-            for (int p = 0; p < G::PASSES; ++p) {
-                const int q = p * G::RPP + sub;
-                const bool h = (hitmask >> q) & 1;
-                const bool bad = (badmask >> q) & 1;
-                V* dst = reinterpret_cast<V*>(out + (base + q) * (int64_t)c.dim);
-#pragma unroll
-                for (int v = 0; v < G::VPL; ++v) {
-                    const uint32_t u = v * G::LPR + l_in;
-                    if (FULL || u < nunits) {
-                        if (h) nt_store(val[p][v], dst + u);
-                        else if (bad) dst[u] = V(0.0f); // rejected id: zero row (kept inline: hoisting it out costs 12 VGPRs and 10 % speed)
-                    }
+            for (int v = 0; v < G::VPL; ++v) {
+                const uint32_t u = v * G::LPR + l_in;
+                if (FULL || u < nunits) {
+                    if (h) nt_store(val[p][v], dst + u);
+                    else if (bad) dst[u] = V(0.0f); // rejected id: zero row (kept inline: hoisting it out costs 12 VGPRs and 10 % speed)
                 }
             }
         }

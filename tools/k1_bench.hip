@@ -220,7 +220,6 @@ int main(int argc, char** argv) {
             ++fake_gen;
             if (dim == 1024 && np == 4) hipLaunchKernelGGL((probe_gather_kernel<1024, 4, 4, false>), dim3(grid), dim3(block), 0, s, h->d, d_ids, out, n, fake_gen);
             else if (dim == 1024 && np == 6) hipLaunchKernelGGL((probe_gather_kernel<1024, 4, 4, true, true>), dim3(grid), dim3(block), 0, s, h->d, d_ids, out, n, fake_gen);
-            else if (dim == 1024 && np == 7) hipLaunchKernelGGL((probe_gather_kernel<1024, 4, 4, true, false, false>), dim3(grid), dim3(block), 0, s, h->d, d_ids, out, n, fake_gen);
             else if (dim == 1024 && np == 5) hipLaunchKernelGGL((probe_gather_kernel<1024, 4, 4, true>), dim3(grid), dim3(block), 0, s, h->d, d_ids, out, n, fake_gen);
             else if (dim == 128 && np == 5) hipLaunchKernelGGL((probe_gather_kernel<128, 4, 4, true>), dim3(grid), dim3(block), 0, s, h->d, d_ids, out, n, fake_gen);
             else if (dim == 1024 && np == 2) hipLaunchKernelGGL((probe_gather_kernel<1024, 4, 2>), dim3(grid), dim3(block), 0, s, h->d, d_ids, out, n, fake_gen);
@@ -228,7 +227,7 @@ int main(int argc, char** argv) {
             else if (dim == 128 && np == 2) hipLaunchKernelGGL((probe_gather_kernel<128, 4, 2>), dim3(grid), dim3(block), 0, s, h->d, d_ids, out, n, fake_gen);
         }});
     };
-    add_prod(2048, 128, 5); add_prod(2048, 128, 7); add_prod(2048, 128, 5); add_prod(2048, 128, 7);
+    add_prod(2048, 128, 4); add_prod(2048, 128, 5); add_prod(2048, 128, 6);
     if (hit_pct == 100) {
         if (dim == 1024) {
             auto add_v2 = [&](const char* nm, auto kern, int grid, int block) {

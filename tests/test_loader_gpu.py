@@ -115,3 +115,14 @@ def test_shared_csc_dataset_from_npy(hiplib, oracle, tmp_path):
     assert torch.equal(blocks[-1].dstdata["labels"], torch.arange(0, 300, device="cuda") % 19)
     cache.close()
     ds.close()
+
+
+def test_example_training_script_runs():
+    """examples/train_synthetic.py: the reference's training loop on the API mirror, end to end (colouring tool included)."""
+    root = os.path.dirname(HERE)
+    out = subprocess.run([sys.executable, os.path.join(root, "examples", "train_synthetic.py"), "--nodes", "60000", "--dim", "64",
+                          "--batch_size", "256", "--epochs", "2", "--cache_size", "4", "--prefetch", "1"],
+                         capture_output=True, text=True, timeout=600, env=dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert out.stdout.count("Epoch Time:") == 2 and "GPU hit ratio:" in out.stdout and "Aggregation time:" in out.stdout
+    assert "final loss" in out.stdout

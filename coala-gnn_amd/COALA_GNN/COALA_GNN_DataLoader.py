@@ -4,8 +4,10 @@ Mirror of COALA-GNN-Setup/COALA_GNN/COALA_GNN_DataLoader.py (reference): COALA_G
 SSD_INFO :80-90, COALA_GNN_DataLoader :92-177 -- same names, arguments, cadence and double buffering.
 `graph_sampler` only needs .sample(graph, seed_ids) returning a tuple whose first element is the int64 input-node
 tensor (a DGL sampler object works when dgl imports; COALA_GNN.sampler.NeighborSampler is the native one)."""
+import collections
 import queue
 import threading
+import time
 from concurrent.futures import ThreadPoolExecutor
 
 import torch
@@ -114,6 +116,7 @@ class COALA_GNN_DataLoader(torch.utils.data.DataLoader):
         self._queue = None
         self._side_stream = None
         self._sample_stream = None
+        self.producer_times = {"schedule": 0.0, "sample": 0.0, "fetch": 0.0, "queue_full": 0.0, "gpu_backlog": 0.0}
         self.refresh_counter = refresh_counter
         self.sampler = graph_sampler
         self.batch_size = batch_size
@@ -168,19 +171,39 @@ class COALA_GNN_DataLoader(torch.utils.data.DataLoader):
             keep_sync = mgr.sync_on_return
             mgr.sync_on_return = False  # the consumer waits on an event instead
 
+            T = self.producer_times  # host seconds per stage, cumulative (diagnostics; tools/prefetch_probe.py)
+            clock = time.perf_counter
+
             def sample_next():
+                t0 = clock()
                 is_last_iter = self.counter + 1 >= self.total_count
-                seeds = self.scheduler.run(is_last_iter)
+                # the colour-counter snapshot (every refresh_counter steps) is read on the fetch stream: ordered after the
+                # fetch enqueued last -- the same point of the sequence as in the serial loader -- and not behind the
+                # consumer's training kernels on the default stream
+                with torch.cuda.stream(self._side_stream):
+                    seeds = self.scheduler.run(is_last_iter)
+                t1 = clock()
                 with torch.cuda.stream(self._sample_stream):
                     batch = self.sampler.sample(self.g, seeds.to(self.device))
                     ev = torch.cuda.Event()
                     ev.record(self._sample_stream)
                 self.counter += 1
+                T["schedule"] += t1 - t0
+                T["sample"] += clock() - t1
                 return batch, ev
 
             nxt = sample_next() if self.counter < self.total_count else None
+            in_flight = collections.deque()
             while nxt is not None:
                 batch, ev_s = nxt
+                # flow control: at most `prefetch` fetches queued on the GPU.  Without it both host threads run many steps
+                # ahead of the device (nothing below waits on the fetch stream), every step in flight pins ~150 MB of rows,
+                # and the first call that does wait pays for the whole backlog.
+                if len(in_flight) >= self.prefetch:
+                    t0 = clock()
+                    in_flight.popleft().synchronize()
+                    T["gpu_backlog"] += clock() - t0
+                t0 = clock()
                 with torch.cuda.stream(self._side_stream):
                     self._side_stream.wait_event(ev_s)
                     for t in _device_tensors(batch):
@@ -188,8 +211,12 @@ class COALA_GNN_DataLoader(torch.utils.data.DataLoader):
                     item = mgr.fetch_feature(batch)
                     ev_f = torch.cuda.Event()
                     ev_f.record(self._side_stream)
+                in_flight.append(ev_f)
+                T["fetch"] += clock() - t0
                 nxt = sample_next() if self.counter < self.total_count else None  # overlaps the fetch just enqueued
+                t0 = clock()
                 self._queue.put((item, ev_f))
+                T["queue_full"] += clock() - t0
             mgr.sync_on_return = keep_sync
             self._queue.put(None)
         except BaseException as e:  # surface producer failures in the consumer
@@ -206,6 +233,8 @@ class COALA_GNN_DataLoader(torch.utils.data.DataLoader):
                 raise StopIteration
             self._queue = queue.Queue(maxsize=self.prefetch)
             if self._side_stream is None:
+                # (stream priorities were tried: a high-priority sampler stream shortens the sampler's host wait from 1.5 to
+                # 0.3 ms under a training load but leaves the epoch time unchanged -- the fetch, not the sampler, is the limit)
                 self._side_stream = torch.cuda.Stream(device=self.device)
                 self._sample_stream = torch.cuda.Stream(device=self.device)
             self._producer = threading.Thread(target=self._producer_loop, daemon=True)

@@ -533,10 +533,14 @@ struct coala_cache {
     coala_cache_profile_t prof{};
     hipStream_t last_stream = nullptr;    // stream of the last bracketed launch (for the empty-bracket calibration)
     uint64_t table_bytes = 0;
-    int k2_grid_cap = kStatBlocks;        // K2 blocks: 64 when the cold tier is host memory.  The link, not the chip, is the limit: 256
-                                          // waves keep ~3 MB of PCIe reads in flight, a full grid only parks waves on every CU.
-                                          // Measured (default bench): 2048 / 512 / 128 / 64 / 16 / 8 blocks -> 53.7 / 53.7 / 56.2 /
-                                          // 56.6 / 55.8 / 43.1 GB/s, and the prefetching epoch step 2.25 -> 2.00 ms.  COALA_K2_GRID
+    int k2_grid_cap = kStatBlocks;        // K2 blocks: 16 when the cold tier is host memory.  The link, not the chip, is the limit, and
+                                          // what matters is the bytes of PCIe reads in flight (blocks x 4 waves x 16 KB): ~1 MB
+                                          // already runs the link at 56.0 GB/s; 4 MB (64 blocks) gives 56.6 GB/s but queues every
+                                          // other host access of the GPU -- AQL packets, kernargs, completion signals of kernels
+                                          // on OTHER streams -- behind ~50 us of reads: a 9-kernel sampler call overlapping the
+                                          // fill took 1.8 ms instead of 0.22 ms, and the prefetching epoch 11.7 s instead of 9.2 s.
+                                          // Full grid: 53.7 GB/s; 8 blocks: 43.1 GB/s.  COALA_K2_GRID overrides.
+    int32_t* color_pin = nullptr;         // pinned staging for coala_cache_color_counts
     int k1_passes = 4;                    // rows(-pairs) in flight per wave in K1 (tunable: COALA_K1_PASSES = 2 | 4)
     int k1_grid_cap = 256 * 8;            // K1 blocks (tunable: COALA_K1_GRID)
     uint64_t rows_total = 0;              // rows submitted since the last stats reset (hits = rows - misses - rejected)
@@ -734,7 +738,7 @@ int coala_cache_create(const coala_cache_config_t* cfg, coala_cache_t** out) {
             hipPointerAttribute_t attr;
             const bool host_tier = hipPointerGetAttributes(&attr, cfg->cold_table) == hipSuccess && attr.type == hipMemoryTypeHost;
             (void)hipGetLastError(); // an unregistered pointer is reported as an error: not ours to keep
-            h->k2_grid_cap = host_tier ? 64 : kStatBlocks;
+            h->k2_grid_cap = host_tier ? 16 : kStatBlocks;
             if (const char* e = getenv("COALA_K2_GRID")) { int g = atoi(e); if (g >= 1 && g <= kStatBlocks) h->k2_grid_cap = g; }
         }
         if (cfg->max_batch) rc = ensure_scratch(h, cfg->max_batch, nullptr);
@@ -760,6 +764,7 @@ int coala_cache_destroy(coala_cache_t* h) {
                     h->wave_counts, h->route_bases};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    if (h->color_pin) (void)hipHostFree(h->color_pin);
     delete h;
     return COALA_OK;
 }
@@ -898,14 +903,18 @@ int coala_cache_color_counts(coala_cache_t* h, int32_t* dst, int32_t n_entries, 
     if (!h->d.color_counters) { memset(dst, 0, (size_t)n_entries * 4); return COALA_OK; }
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipSetDevice(h->cfg.device));
-    HIPCHK(hipMemcpyAsync(dst, h->d.color_counters, (size_t)n_entries * 4, hipMemcpyDeviceToHost, s));
+    // staged through pinned memory owned by the handle: a D2H copy into pageable memory waits for every queue of the device
+    // (measured: 11 ms per call when a prefetching loader had run ahead), this one only for `stream`
+    if (!h->color_pin) HIPCHK(hipHostMalloc((void**)&h->color_pin, ((size_t)h->cfg.num_colors + 1) * 4, hipHostMallocDefault));
+    HIPCHK(hipMemcpyAsync(h->color_pin, h->d.color_counters, (size_t)n_entries * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    memcpy(dst, h->color_pin, (size_t)n_entries * 4);
     return COALA_OK;
 }
 
 static int read_stats(coala_cache_t* h, hipStream_t s, uint64_t* hit, uint64_t* miss, uint64_t* bad, bool reset) {
     std::vector<unsigned long long> part((size_t)kStatBlocks * 2);
-    HIPCHK(hipMemcpyAsync(part.data(), h->d.stats, part.size() * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(part.data(), h->d.stats, part.size() * 8, hipMemcpyDeviceToHost, s)); // end of epoch: a device-wide wait is fine
     if (reset) HIPCHK(hipMemsetAsync(h->d.stats, 0, part.size() * 8, s));
     HIPCHK(hipStreamSynchronize(s));
     uint64_t m = 0, b = 0;

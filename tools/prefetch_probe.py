@@ -26,6 +26,18 @@ for train in (False, True):
     loader = COALA_GNN_DataLoader(SSD_INFO(1, 4096, 1024, 0), nd, g, sampler, batch, dim, fan, 4096, "cuda:0", cache_backend="isolated", sim_buf=table, num_rows=rows, prefetch=2)
     model = SageMean(dim, 128, 19).cuda(); opt = torch.optim.Adam(model.parameters(), 1e-3); lossf = torch.nn.CrossEntropyLoss()
     n = 0; wait = 0.0; t_train = 0.0
+    ST = {}
+    def wrap(obj, name, key):
+        f = getattr(obj, name)
+        def g(*a, **k):
+            t = time.perf_counter()
+            try: return f(*a, **k)
+            finally: ST[key] = ST.get(key, 0.0) + time.perf_counter() - t
+        setattr(obj, name, g)
+    wrap(loader.COALA_GNN_Manager.COALA_GNN_Cache, "get_cache_data", "get_cache_data")
+    wrap(nd, "parse_domain_training_nodes", "parse(in pool)")
+    wrap(nd, "gather_cache_meta", "gather_meta(in pool)")
+    wrap(comm, "broadcast_training_nodes", "broadcast")
     torch.cuda.synchronize(); t0 = time.perf_counter()
     it = iter(loader)
     while True:
@@ -39,4 +51,6 @@ for train in (False, True):
         n += 1
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print(f"train={train}: {n} steps, {dt/n*1e3:.3f} ms/step, consumer wait {wait/n*1e3:.3f} ms/step, consumer python in train {t_train/n*1e3:.3f} ms/step")
+    print("   producer host ms/step:", {k: round(v / n * 1e3, 3) for k, v in loader.producer_times.items()})
+    print("   scheduler pieces ms/step:", {k: round(v / n * 1e3, 3) for k, v in ST.items()})
     del loader, nd

@@ -54,6 +54,11 @@ def parse_args():
     ap.add_argument("--epoch-steps", type=int, default=-1,
                     help="end-to-end leg (loader + GraphSAGE step): -1 = one FULL epoch per mode (measured, not extrapolated), "
                          "k > 0 = k steps extrapolated to an epoch, 0 = skip")
+    ap.add_argument("--epoch-prefetch-multi", action="store_true",
+                    help="N>1: also run the epoch leg with the prefetching loader (the exchange's RCCL communicator and DDP's are then "
+                         "driven from two host threads; not validated on multi-GPU hardware yet, hence opt-in)")
+    ap.add_argument("--epoch-timeout", type=float, default=420.0,
+                    help="N>1: seconds after which the epoch leg is abandoned and the JSON line printed without it")
     ap.add_argument("--exchange", type=str, default=None, choices=["torch", "native"],
                     help="N>1: torch.distributed all_to_all_single (default) or the fused native RCCL call")
     ap.add_argument("--cold-tier", type=str, default="host", choices=["host", "hbm"],
@@ -282,11 +287,6 @@ def main():
                            "hit_ratio": round(h2 / max(h2 + m2, 1), 4), "alg_bytes_per_launch": int(b2 / l2),
                            "note": "untimed extra leg: every row a hit (pre-warmed unique uniform ids)"}
 
-    # ---------------------------------------------------------------- extra leg (N=1): end-to-end training steps
-    epoch = None
-    if world == 1 and args.mode == "minibatch" and args.epoch_steps != 0:
-        epoch = run_epoch_leg(args, comm, graph, sampler, table, device, fanout, steps_per_epoch)
-
     # the kernel that dominates the STEP TIME on this workload is the cold fill, bound by the host link, not by HBM
     fill_launches = max(prof.fill_launches, 1)
     fill_us = prof.fill_ms / fill_launches * 1e3
@@ -322,9 +322,45 @@ def main():
             "roofline": roofline,
             "roofline_allhit": roofline_allhit,
             "roofline_cold_fill": roofline_cold,
-            "epoch": epoch,
+            "epoch": None,
             "cpu_baseline": cpu_baseline,
         }
+    else:
+        line = None
+
+    # ---------------------------------------------------------------- extra leg: end-to-end training steps (epoch time)
+    # Runs last.  At N>1 it is new ground for every collective path at once (exchange + DDP), so a watchdog guarantees the
+    # JSON line: if the leg does not finish in --epoch-timeout seconds every rank gives up and rank 0 prints what it has.
+    if args.mode == "minibatch" and args.epoch_steps != 0:
+        partial = {}
+        watchdog = None
+        if world > 1:
+            import threading
+
+            def give_up():
+                if rank == 0:
+                    partial["error"] = f"epoch leg abandoned after {args.epoch_timeout:.0f} s"
+                    line["epoch"] = partial
+                    print(json.dumps(line), flush=True)
+                os._exit(0)
+            watchdog = threading.Timer(args.epoch_timeout, give_up)
+            watchdog.daemon = True
+            watchdog.start()
+        try:
+            epoch = run_epoch_leg(args, comm, graph, sampler, table, device, fanout, steps_per_epoch, backend=backend,
+                                  cold_partitioned=cold_partitioned, world=world, dev_index=dev_index, single_dev=single_dev,
+                                  out=partial)
+        except Exception as e:  # noqa: BLE001 -- the headline number must still be reported
+            if world == 1:
+                raise
+            log(f"epoch leg failed: {e!r}")
+            partial["error"] = repr(e)
+            epoch = partial
+        if watchdog is not None:
+            watchdog.cancel()
+        if rank == 0:
+            line["epoch"] = epoch
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
@@ -333,15 +369,36 @@ def main():
         comm.destroy_process_group()
 
 
-def run_epoch_leg(args, comm, graph, sampler, table, device, fanout, steps_per_epoch):
-    """distribute -> sample -> fetch -> GraphSAGE fwd/bwd/Adam per step, through COALA_GNN_DataLoader, serial (the
-    reference's __next__) and with the prefetching producer; epoch time extrapolated to steps_per_epoch."""
+def run_epoch_leg(args, comm, graph, sampler, table, device, fanout, steps_per_epoch, backend="isolated", cold_partitioned=False,
+                  world=1, dev_index=0, single_dev=False, out=None):
+    """distribute -> sample -> fetch -> GraphSAGE fwd/bwd/Adam per step, through COALA_GNN_DataLoader: serial (the reference's
+    __next__) and with the prefetching producer.  N>1: the same loop on every rank (global batch = batch x N, the partitioned
+    cache behind the RCCL exchange, DistributedDataParallel model as in examples/sbatch_ssd_gnn_train.py:112); the time of a
+    leg is the MAX over ranks."""
     import tempfile
     from COALA_GNN import COALA_GNN_DataLoader, Node_Distributor, SSD_INFO
     from COALA_GNN.harness import SageMean, train_steps
     from COALA_GNN.synthetic import block_colors
-    out = {"model": "GraphSAGE 2-layer mean, hidden 128, 19 classes, Adam (torch; out of scope, harness only)",
-           "per_step": "distribute + sample + fetch_feature + forward/backward/optimizer", "steps_per_epoch": steps_per_epoch}
+    out = {} if out is None else out
+    out.update({"model": "GraphSAGE 2-layer mean, hidden 128, 19 classes, Adam (torch; out of scope, harness only)"
+                         + (", DistributedDataParallel" if world > 1 else ""),
+                "per_step": "distribute + sample + fetch_feature + forward/backward/optimizer", "steps_per_epoch": steps_per_epoch,
+                "cache_backend": backend})
+    modes = [("serial", 0), ("prefetch", 2)]
+    if world > 1 and not args.epoch_prefetch_multi:
+        modes = modes[:1]
+        out["prefetch"] = None
+        out["note"] = "N>1 runs the serial loader only; --epoch-prefetch-multi adds the prefetching one"
+
+    def across_ranks(secs, nodes):
+        if world == 1:
+            return secs, nodes
+        t = torch.tensor([secs, float(nodes)], dtype=torch.float64, device="cpu" if single_dev else device)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(tmax[0]), int(t[1])
+
     with tempfile.TemporaryDirectory() as tmp:
         color, tk, sc, _ = block_colors(args.rows, nodes_per_color=4096)
         files = [os.path.join(tmp, f) for f in ("color.npy", "topk.npy", "score.npy")]
@@ -349,18 +406,24 @@ def run_epoch_leg(args, comm, graph, sampler, table, device, fanout, steps_per_e
         del color
         n_train = int(0.6 * args.rows)
         full = args.epoch_steps < 0
-        need = n_train if full else (args.epoch_steps * 2 + 260) * args.batch
+        need = n_train if full else (args.epoch_steps * 2 + 260) * args.batch * world
         train_ids = torch.randperm(n_train, generator=torch.Generator().manual_seed(1))[: min(n_train, need)]
         graph.ndata["labels"] = (torch.arange(args.rows, device=device) * 7) % 19
-        for name, prefetch in (("serial", 0), ("prefetch", 2)):
+        for name, prefetch in modes:
             nd = Node_Distributor(comm, train_ids, args.batch, *files, parsing_method="baseline")
             loader = COALA_GNN_DataLoader(SSD_INFO(1, args.dim * 4, 1024, 0), nd, graph, sampler, args.batch, args.dim, fanout,
-                                          args.cache_mb, device, cache_backend="isolated", sim_buf=table, num_rows=args.rows,
-                                          prefetch=prefetch)
+                                          args.cache_mb, device, cache_backend=backend, sim_buf=table, num_rows=args.rows,
+                                          prefetch=prefetch, cold_partitioned=cold_partitioned)
+            torch.manual_seed(0)  # identical initial weights on every rank
             model = SageMean(args.dim, 128, 19).to(device)
+            if world > 1:
+                # the development hook (all ranks on one GPU) cannot use RCCL: gradients go through a gloo group there
+                pg = dist.new_group(backend="gloo") if single_dev else None
+                model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev_index], process_group=pg)
             opt = torch.optim.Adam(model.parameters(), lr=1e-3)
             if full:  # one whole epoch from a cold cache, as the reference's "Epoch Time" of epoch 0
                 steps, secs, nodes = train_steps(loader, model, opt, 1 << 60, device)
+                secs, nodes = across_ranks(secs, nodes)
                 ms = secs / max(steps, 1) * 1e3
                 out[name] = {"steps": steps, "ms_per_step": round(ms, 3), "epoch_time_s_measured": round(secs, 2),
                              "sampled_nodes": int(nodes)}
@@ -372,6 +435,7 @@ def run_epoch_leg(args, comm, graph, sampler, table, device, fanout, steps_per_e
                 continue
             train_steps(loader, model, opt, 100, device)                       # warm the cache and the allocator
             steps, secs, nodes = train_steps(loader, model, opt, args.epoch_steps, device)
+            secs, nodes = across_ranks(secs, nodes)
             ms = secs / max(steps, 1) * 1e3
             out[name] = {"steps": steps, "ms_per_step": round(ms, 3), "epoch_time_s_extrapolated": round(ms * steps_per_epoch / 1e3, 2),
                          "sampled_nodes_per_step": round(nodes / max(steps, 1), 1)}

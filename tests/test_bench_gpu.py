@@ -1,0 +1,47 @@
+"""bench.py contract (the driver's entry point): one JSON line with the required keys, at N=1 and -- through the one-GPU
+development hook -- under torch.distributed.run with 2 ranks, including the end-to-end epoch leg."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--rows", "300000", "--prewarm", "20", "--steps", "10", "--warmup", "3", "--cache-mb", "256", "--epoch-steps", "12",
+         "--cpu-baseline-batches", "2", "--allhit-launches", "5"]
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline", "cpu_baseline"}
+
+
+def _line(out):
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-1500:]
+    return json.loads(lines[0])
+
+
+def test_bench_single_gpu_contract():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *SMALL], capture_output=True, text=True, timeout=900)
+    d = _line(out)
+    assert REQUIRED <= set(d) and d["n_gpus"] == 1 and d["steps"] == 10 and d["warmup"] == 3 and d["value"] > 0
+    assert d["vs_baseline"] is None and d["scaling"] == "weak" and "workload" in d["config"]
+    r = d["roofline"]
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(r) and r["bound"] == "hbm" and 0 < r["frac"] < 1
+    c = d["cpu_baseline"]
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(c) and c["kind"] == "port" and c["value"] > 0
+    e = d["epoch"]
+    assert e["serial"]["steps"] == 12 and e["prefetch"]["steps"] == 12 and e["serial"]["ms_per_step"] > 0
+
+
+def test_bench_two_ranks_on_one_gpu_with_epoch_leg():
+    env = dict(os.environ, COALA_BENCH_SINGLE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29571", os.path.join(ROOT, "bench.py"), "--gpus", "2", *SMALL, "--epoch-prefetch-multi"]
+    d = _line(subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env))
+    assert d["n_gpus"] == 2 and d["config"]["cache_backend"] == "nccl" and d["config"]["TEST_HOOK_single_device"] is True
+    assert d["cpu_baseline"] is None and d["value"] > 0
+    e = d["epoch"]
+    assert "error" not in e and e["serial"]["steps"] == 12 and e["prefetch"]["steps"] == 12
+    assert "DistributedDataParallel" in e["model"]

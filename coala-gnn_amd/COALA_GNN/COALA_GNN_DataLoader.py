@@ -107,10 +107,13 @@ class SSD_INFO(object):  # COALA_GNN_DataLoader.py:80-90
 class COALA_GNN_DataLoader(torch.utils.data.DataLoader):
     def __init__(self, SSD_info, node_distributor, graph, graph_sampler, batch_size, dim, fan_out, cache_size, device,
                  refresh_counter=10, cache_backend="nvshmem", sim_buf=None, shuffle=False, num_rows=None, profile=False,
-                 prefetch=0, cold_partitioned=False):
+                 prefetch=0, cold_partitioned=False, sync_fetch=False):
         # like the reference, torch's DataLoader.__init__ is never called: this is a plain iterator
         # prefetch = 0: the reference's strictly serial __next__ (:149-167).  prefetch = k > 0: a producer thread runs
         # distribute -> sample -> fetch for the next k steps on its own HIP stream while the consumer trains (SURVEY f-2).
+        # sync_fetch = True: the reference's fetch_feature, which returns only when the rows are in place.  False (default):
+        # the fetch is only ENQUEUED on the current stream -- the training step that follows is ordered behind it by the stream,
+        # and its launch overhead (about 1 ms of host time for the GraphSAGE step) overlaps the fetch instead of following it.
         self.prefetch = int(prefetch)
         self._producer = None
         self._queue = None
@@ -132,6 +135,7 @@ class COALA_GNN_DataLoader(torch.utils.data.DataLoader):
             batch_size=batch_size, fan_out=fan_out, dim=dim, MPI_comm_manager=node_distributor.comm_manager, device=device,
             cache_backend=cache_backend, sim_buf=sim_buf, num_rows=num_rows, profile=profile,
             cold_partitioned=cold_partitioned, out_ring=self.prefetch + 2)  # batches alive at once: consumer + queue + producer
+        self.COALA_GNN_Manager.sync_on_return = bool(sync_fetch)
         self.scheduler = COALA_GNN_Node_Distribution_Scheduler(node_distributor=self.node_distributor,
                                                                ssd_gnn_manager=self.COALA_GNN_Manager,
                                                                refresh_counter=self.refresh_counter)

@@ -171,7 +171,10 @@ class COALA_GNN_Manager(object):
         self.sim_buf = sim_buf
         self.is_simulation = sim_buf is not None
         self.aggregation_timer = 0.0
-        self.sync_on_return = True   # set False to keep fetch_feature fully stream-ordered (no host wait at all)
+        # True (the reference's behaviour): fetch_feature returns when the rows are there and the aggregation timer is host
+        # wall time.  False: fully stream-ordered, no host wait; the timer is then fed by a pair of HIP events per call.
+        self.sync_on_return = True
+        self._agg_events = []
         if not self.is_simulation:
             raise RuntimeError("sim_buf is None: the NVMe/BaM tier is out of scope here; pass the pinned feature table "
                                "(the reference's --feat_cpu mode, used by every published script)")
@@ -231,6 +234,10 @@ class COALA_GNN_Manager(object):
         index_size = len(index)
         index_ptr = index.data_ptr()
         fetch_start = time.time()
+        ev_pair = None
+        if not self.sync_on_return:
+            ev_pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev_pair[0].record()
 
         if self.cache_backend == "nvshmem":
             return_torch = self.NVshmem_tensor_manager.get_batch_tensor([index_size, self.dim])
@@ -252,8 +259,25 @@ class COALA_GNN_Manager(object):
         # the rows are there, so the aggregation timer measures the whole fetch (COALA_GNN_Manager.py:122,134).
         if self.sync_on_return:
             torch.cuda.current_stream().synchronize()
-        self.aggregation_timer += (time.time() - fetch_start)
+            self.aggregation_timer += (time.time() - fetch_start)
+        else:
+            ev_pair[1].record()
+            self._agg_events.append(ev_pair)
+            if len(self._agg_events) >= 64:
+                self._fold_events(wait=False)
         return (*batch, return_torch)
+
+    def _fold_events(self, wait):
+        """Move finished (start, end) event pairs into the aggregation timer; with wait=True, all of them."""
+        keep = []
+        for a, b in self._agg_events:
+            if wait:
+                b.synchronize()
+            if b.query():
+                self.aggregation_timer += a.elapsed_time(b) * 1e-3
+            else:
+                keep.append((a, b))
+        self._agg_events = keep
 
     def get_cache_data(self, ptr, n_entries=None):
         self.COALA_GNN_Cache.get_cache_data(ptr, n_entries)
@@ -262,6 +286,7 @@ class COALA_GNN_Manager(object):
         self.COALA_GNN_Cache.print_stats()
 
     def get_aggregate_time(self):
+        self._fold_events(wait=True)
         return self.aggregation_timer
 
     def __del__(self):  # :226-230

@@ -96,8 +96,13 @@ def main():
         os.environ["COALA_CACHE_GROUP_BACKEND"] = "gloo"
 
     import __graft_entry__ as entry
-    if rank == 0:
-        entry._load_build_module().build_lib()
+    bm = entry._load_build_module()
+    if local_rank == 0:
+        bm.build_lib()          # no-op when the in-tree library is up to date (the usual case: it travels with the snapshot)
+    else:                       # the other ranks of the node wait for it instead of loading a missing / stale library
+        t_wait = time.time()
+        while bm.needs_build() and time.time() - t_wait < 900:
+            time.sleep(1.0)
     from COALA_GNN import MPI_Comm_Manager
     from COALA_GNN.COALA_GNN_Manager import COALA_GNN_Manager
     from COALA_GNN.synthetic import PinnedFeatureTable, feature_rows_torch, fill_table, fill_table_partition, powerlaw_csc

@@ -64,6 +64,10 @@ class AllToAllExchange(object):
         self.counts = torch.zeros(world, dtype=torch.int64, device=device)
         self.offsets = torch.zeros(world + 1, dtype=torch.int64, device=device)
         self.recv_counts = torch.zeros(world, dtype=torch.int64, device=device)
+        on_gpu = str(device).startswith("cuda")
+        self._both_dev = torch.zeros((2, world), dtype=torch.int64, device=device)
+        # pinned: a D2H copy into pageable memory is staged by the runtime and can wait on more than this stream
+        self._both_host = torch.zeros((2, world), dtype=torch.int64, pin_memory=on_gpu)
         self.last_send_counts = None
         self.last_recv_counts = None
 
@@ -85,8 +89,12 @@ class AllToAllExchange(object):
         mp = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
         ops.route(idx_ptr, n, self.world, node.data_ptr(), mp.data_ptr(), self.counts.data_ptr(), self.offsets.data_ptr(), 0)
         self._a2a(self.recv_counts, self.counts)
-        both = torch.stack([self.counts, self.recv_counts]).cpu()  # the one host synchronisation of the step
-        send_c, recv_c = both[0].tolist(), both[1].tolist()
+        self._both_dev[0].copy_(self.counts)
+        self._both_dev[1].copy_(self.recv_counts)
+        self._both_host.copy_(self._both_dev, non_blocking=True)
+        if self._both_dev.is_cuda:
+            torch.cuda.current_stream().synchronize()  # the one host synchronisation of the step
+        send_c, recv_c = self._both_host[0].tolist(), self._both_host[1].tolist()
         total_recv = int(sum(recv_c))
         recv_ids = torch.empty(max(total_recv, 1), dtype=torch.int64, device=dev)
         self._a2a(recv_ids[:total_recv], node[:n], recv_c, send_c)

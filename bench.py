@@ -264,7 +264,6 @@ def main():
         "rows_per_launch": round(prof.gather_rows / launches, 1), "hits_per_launch": round(prof.gather_hits / launches, 1),
         "alg_bytes_per_launch": int(alg_bytes / launches),
         "cold_fill_avg_us": round(prof.fill_ms / max(prof.fill_launches, 1) * 1e3, 2),
-        "rank_avg_us": round(prof.rank_ms / max(prof.fill_launches, 1) * 1e3, 2),
     }
 
     # ---------------------------------------------------------------- extra leg (N=1): the hit path alone

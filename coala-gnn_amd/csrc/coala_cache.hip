@@ -738,7 +738,12 @@ int coala_cache_create(const coala_cache_config_t* cfg, coala_cache_t** out) {
             hipPointerAttribute_t attr;
             const bool host_tier = hipPointerGetAttributes(&attr, cfg->cold_table) == hipSuccess && attr.type == hipMemoryTypeHost;
             (void)hipGetLastError(); // an unregistered pointer is reported as an error: not ours to keep
-            h->k2_grid_cap = host_tier ? 16 : kStatBlocks;
+            // host tier: ~1 MB of reads in flight (blocks x 4 waves x rows-per-wave x line bytes).  A wave holds 16 KB of 4-KiB lines
+            // but only 4 KB of 512-B or 1-KiB lines, and with short lines the per-chunk ranking latency dominates, so the
+            // count scales with the line size: 16 / 32 / 64 / 64 blocks for cache_dim 1024 / 512 / 256 / 128
+            // (measured at cache_dim 128, 111 M x 128 table: 32 / 64 / 128 blocks -> 42.9 / 55.2 / 52.7 GB/s; 16 -> 22.4).
+            const int host_blocks = std::min(64, std::max(16, 16 * 1024 / (int)d.cache_dim));
+            h->k2_grid_cap = host_tier ? host_blocks : kStatBlocks;
             if (const char* e = getenv("COALA_K2_GRID")) { int g = atoi(e); if (g >= 1 && g <= kStatBlocks) h->k2_grid_cap = g; }
         }
         if (cfg->max_batch) rc = ensure_scratch(h, cfg->max_batch, nullptr);

@@ -273,94 +273,117 @@ __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src) {
 
 template <int CD, int VEC, int NP = 4>
 __global__ __launch_bounds__(256) void miss_fill_kernel(CacheDev c, const int64_t* __restrict__ idx, float* __restrict__ out,
-                                                        int64_t n) {
+                                                        int64_t n, int tile_rows) {
+    // A wave reads the verdicts of tile_rows rows at once (one byte per lane; tile_rows = R or 64) and then works through
+    // the tile chunk by chunk (R rows), skipping chunks without a miss on a scalar mask.  With tile_rows = R this is one
+    // verdict load per chunk: fine when the grid is wide (HBM cold tier).  Behind the 16..64-block grid of the host tier it
+    // made a batch with few misses latency-bound (123,904 rows, all hits: 484 dependent loads per wave = 220 us of nothing).
     using G = Geo<CD, VEC, NP>;
     using V = typename VecT<VEC>::type;
     constexpr int R = G::R;
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
-    const int64_t n_chunks = (n + R - 1) / R;
+    const int64_t n_tiles = (n + tile_rows - 1) / tile_rows;
+    const int chunks_per_tile = tile_rows / R;
     const uint32_t nunits = c.dim / VEC;
     const int sub = (G::RPP == 2) ? (lane >> 5) : 0;
     const int l_in = lane & (G::LPR - 1);
     uint32_t my_miss = 0, my_bad = 0;
 
-    for (int64_t chunk = wave; chunk < n_chunks; chunk += n_waves) {
-        const int64_t base = chunk * R;
-        const int64_t pos_l = base + lane;
-        const uint8_t st = (lane < R && pos_l < n) ? c.row_state[pos_l] : (uint8_t)0;
-        const uint64_t live_mask = __ballot(st == 1);
+    constexpr int U = 4; // verdict loads in flight per wave: the scan of a batch without misses is a chain of load latencies
+    for (int64_t tile0 = wave; tile0 < n_tiles; tile0 += n_waves * U) {
+      uint32_t st_pack = 0; // the U verdict bytes of this lane, one per tile
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+          const int64_t p = (tile0 + u * n_waves) * tile_rows + lane;
+          const uint8_t v = (tile0 + u * n_waves < n_tiles && lane < tile_rows && p < n) ? c.row_state[p] : (uint8_t)0;
+          st_pack |= (uint32_t)v << (8 * u);
+      }
+      if (!__ballot(st_pack != 0)) continue; // nothing but hits in these U tiles
+#pragma nounroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t tile_base = (tile0 + u * n_waves) * tile_rows;
+        const int64_t pos_l = tile_base + lane;
+        const uint8_t st = (uint8_t)(st_pack >> (8 * u));
+        const uint64_t tile_mask = __ballot(st == 1);
         if (st) c.row_state[pos_l] = 0; // leave the array clean for the next batch
         my_miss += (st == 1);
         my_bad += (st == 2);
-        if (!live_mask) continue;
-        // ---- lanes q < R holding a miss: rank it inside its set and pick the way
-        uint32_t slot_l = 0, win_l = 0;
-        uint64_t id_l = 0;
-        if (st == 1) {
-            id_l = (uint64_t)idx[pos_l];
-            const uint64_t set = set_of(c, id_l);
-            uint32_t cur = (uint32_t)c.set_head[set]; // tagged with this generation: this row was pushed on it by K1
-            uint32_t total = 0, rank = 0;
-            while (cur) {
-                const uint32_t p2 = cur - 1;
-                ++total;
-                rank += (p2 < (uint32_t)pos_l) ? 1u : 0u;
-                cur = c.miss_next[p2];
+        if (!tile_mask) continue;
+        for (int ck = 0; ck < chunks_per_tile; ++ck) {
+            const uint32_t live_mask = (uint32_t)(tile_mask >> (ck * R)) & ((1u << R) - 1u);
+            if (!live_mask) continue;
+            const int lane0 = ck * R;              // lanes lane0 .. lane0+R-1 hold this chunk's rows
+            const int64_t base = tile_base + lane0;
+            // ---- the chunk's lanes holding a miss: rank it inside its set and pick the way
+            uint32_t slot_l = 0, win_l = 0;
+            uint64_t id_l = 0;
+            if (st == 1 && lane >= lane0 && lane < lane0 + R) {
+                id_l = (uint64_t)idx[pos_l];
+                const uint64_t set = set_of(c, id_l);
+                uint32_t cur = (uint32_t)c.set_head[set]; // tagged with this generation: this row was pushed on it by K1
+                uint32_t total = 0, rank = 0;
+                while (cur) {
+                    const uint32_t p2 = cur - 1;
+                    ++total;
+                    rank += (p2 < (uint32_t)pos_l) ? 1u : 0u;
+                    cur = c.miss_next[p2];
+                }
+                const uint32_t cnt0 = c.set_cnt[set] - total;                       // value before this batch
+                const uint32_t way = (cnt0 + rank) & (COALA_WAYS - 1);              // isolated_cache.h:203
+                slot_l = (uint32_t)(set * COALA_WAYS) + way;
+                win_l = (rank + COALA_WAYS >= total) ? 1u : 0u;                     // nobody later in the batch lands here
+                if (win_l) {
+                    c.keys[slot_l] = id_l;                                          // isolated_cache.h:434
+                    if (c.color_counters) {
+                        // the pre-batch occupant leaves (:427-429), the winner enters (:437-441); rows that were inserted
+                        // and overwritten again inside this batch cancel out
+                        const int32_t col = c.node_color[id_l];
+                        atomicSub(c.color_counters + c.color_meta[slot_l], 1);
+                        atomicAdd(c.color_counters + col, 1);
+                        c.color_meta[slot_l] = (uint32_t)col;
+                    }
+                }
             }
-            const uint32_t cnt0 = c.set_cnt[set] - total;                       // value before this batch
-            const uint32_t way = (cnt0 + rank) & (COALA_WAYS - 1);              // isolated_cache.h:203
-            slot_l = (uint32_t)(set * COALA_WAYS) + way;
-            win_l = (rank + COALA_WAYS >= total) ? 1u : 0u;                     // nobody later in the batch lands here
-            if (win_l) {
-                c.keys[slot_l] = id_l;                                          // isolated_cache.h:434
-                if (c.color_counters) {
-                    // the pre-batch occupant leaves (:427-429), the winner enters (:437-441); rows that were inserted and
-                    // overwritten again inside this batch cancel out
-                    const int32_t col = c.node_color[id_l];
-                    atomicSub(c.color_counters + c.color_meta[slot_l], 1);
-                    atomicAdd(c.color_counters + col, 1);
-                    c.color_meta[slot_l] = (uint32_t)col;
+            // ---- every lane learns the rows of its pass
+            V val[G::PASSES][G::VPL];
+            uint32_t slot_[G::PASSES];
+            uint64_t id[G::PASSES];
+            bool live[G::PASSES], winner[G::PASSES];
+#pragma unroll
+            for (int p = 0; p < G::PASSES; ++p) {
+                const int q = p * G::RPP + sub;
+                live[p] = (live_mask >> q) & 1;
+                slot_[p] = (uint32_t)__shfl((int)slot_l, lane0 + q);
+                winner[p] = __shfl((int)win_l, lane0 + q) != 0;
+                id[p] = shfl64(id_l, lane0 + q);
+            }
+#pragma unroll
+            for (int p = 0; p < G::PASSES; ++p) {
+                const V* src = reinterpret_cast<const V*>(c.cold + cold_row_of(c, id[p]) * (uint64_t)c.dim); // cold stride = dim
+#pragma unroll
+                for (int v = 0; v < G::VPL; ++v) {
+                    const uint32_t u = v * G::LPR + l_in;
+                    if (live[p] && u < nunits) val[p][v] = nt_load(src + u);
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < G::PASSES; ++p) {
+                const int q = p * G::RPP + sub;
+                V* dst = reinterpret_cast<V*>(out + (uint64_t)(base + q) * c.dim);
+                V* line = reinterpret_cast<V*>(c.lines + (uint64_t)slot_[p] * CD);
+#pragma unroll
+                for (int v = 0; v < G::VPL; ++v) {
+                    const uint32_t u = v * G::LPR + l_in;
+                    if (live[p] && u < nunits) {
+                        nt_store(val[p][v], dst + u);
+                        if (winner[p]) nt_store(val[p][v], line + u);
+                    }
                 }
             }
         }
-        // ---- every lane learns the rows of its pass
-        V val[G::PASSES][G::VPL];
-        uint32_t slot_[G::PASSES];
-        uint64_t id[G::PASSES];
-        bool live[G::PASSES], winner[G::PASSES];
-#pragma unroll
-        for (int p = 0; p < G::PASSES; ++p) {
-            const int q = p * G::RPP + sub;
-            live[p] = (live_mask >> q) & 1;
-            slot_[p] = (uint32_t)__shfl((int)slot_l, q);
-            winner[p] = __shfl((int)win_l, q) != 0;
-            id[p] = shfl64(id_l, q);
-        }
-#pragma unroll
-        for (int p = 0; p < G::PASSES; ++p) {
-            const V* src = reinterpret_cast<const V*>(c.cold + cold_row_of(c, id[p]) * (uint64_t)c.dim); // cold stride = dim
-#pragma unroll
-            for (int v = 0; v < G::VPL; ++v) {
-                const uint32_t u = v * G::LPR + l_in;
-                if (live[p] && u < nunits) val[p][v] = nt_load(src + u);
-            }
-        }
-#pragma unroll
-        for (int p = 0; p < G::PASSES; ++p) {
-            const int q = p * G::RPP + sub;
-            V* dst = reinterpret_cast<V*>(out + (uint64_t)(base + q) * c.dim);
-            V* line = reinterpret_cast<V*>(c.lines + (uint64_t)slot_[p] * CD);
-#pragma unroll
-            for (int v = 0; v < G::VPL; ++v) {
-                const uint32_t u = v * G::LPR + l_in;
-                if (live[p] && u < nunits) {
-                    nt_store(val[p][v], dst + u);
-                    if (winner[p]) nt_store(val[p][v], line + u);
-                }
-            }
-        }
+      }
     }
     // miss / rejected totals (isolated_cache.h:471-472): a running sum per block, owned by that block -- no atomics
     __shared__ uint32_t s_m[256 / 64], s_b[256 / 64];
@@ -541,6 +564,7 @@ struct coala_cache {
                                           // fill took 1.8 ms instead of 0.22 ms, and the prefetching epoch 11.7 s instead of 9.2 s.
                                           // Full grid: 53.7 GB/s; 8 blocks: 43.1 GB/s.  COALA_K2_GRID overrides.
     int32_t* color_pin = nullptr;         // pinned staging for coala_cache_color_counts
+    int k2_tile_rows = 0;                 // rows per verdict tile of K2: 64 for a host cold tier, 0 = one chunk (COALA_K2_TILE_ROWS)
     int k1_passes = 4;                    // rows(-pairs) in flight per wave in K1 (tunable: COALA_K1_PASSES = 2 | 4)
     int k1_grid_cap = 256 * 8;            // K1 blocks (tunable: COALA_K1_GRID)
     uint64_t rows_total = 0;              // rows submitted since the last stats reset (hits = rows - misses - rejected)
@@ -744,6 +768,8 @@ int coala_cache_create(const coala_cache_config_t* cfg, coala_cache_t** out) {
             // (measured at cache_dim 128, 111 M x 128 table: 32 / 64 / 128 blocks -> 42.9 / 55.2 / 52.7 GB/s; 16 -> 22.4).
             const int host_blocks = std::min(64, std::max(16, 16 * 1024 / (int)d.cache_dim));
             h->k2_grid_cap = host_tier ? host_blocks : kStatBlocks;
+            h->k2_tile_rows = host_tier ? 64 : 0;
+            if (const char* e = getenv("COALA_K2_TILE_ROWS")) { int t = atoi(e); if (t == 0 || t == 8 || t == 16 || t == 32 || t == 64) h->k2_tile_rows = t; }
             if (const char* e = getenv("COALA_K2_GRID")) { int g = atoi(e); if (g >= 1 && g <= kStatBlocks) h->k2_grid_cap = g; }
         }
         if (cfg->max_batch) rc = ensure_scratch(h, cfg->max_batch, nullptr);
@@ -827,7 +853,10 @@ static int read_feature_impl(coala_cache_t* h, float* out, const int64_t* idx, i
         }
         {
             ProfScope ps(h, s, 2, 0);
-            hipLaunchKernelGGL((miss_fill_kernel<CD, VEC>), dim3(grid_for(chunks, 4, h->k2_grid_cap)), dim3(256), 0, s, d, idx, out, n);
+            // verdict tile: 64 rows behind the narrow host-tier grid, one chunk behind the wide HBM-tier grid (see the kernel)
+            const int tile_rows = h->k2_tile_rows > 0 ? h->k2_tile_rows : G::R;
+            hipLaunchKernelGGL((miss_fill_kernel<CD, VEC>), dim3(grid_for((n + tile_rows - 1) / tile_rows, 4, h->k2_grid_cap)), dim3(256), 0,
+                               s, d, idx, out, n, tile_rows);
         }
         h->rows_total += (uint64_t)n;
         return COALA_OK;

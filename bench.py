@@ -346,7 +346,7 @@ def main():
 
             def give_up():
                 if rank == 0:
-                    partial["error"] = f"epoch leg abandoned after {args.epoch_timeout:.0f} s"
+                    partial["error"] = f"extra legs abandoned by the watchdog after {args.epoch_timeout:.0f} s"
                     line["epoch"] = partial
                     print(json.dumps(line), flush=True)
                 os._exit(0)
@@ -363,10 +363,22 @@ def main():
             log(f"epoch leg failed: {e!r}")
             partial["error"] = repr(e)
             epoch = partial
-        if watchdog is not None:
-            watchdog.cancel()
         if rank == 0:
             line["epoch"] = epoch
+        # ---------------------------------------------------------------- extra leg (N>1): BASELINE.json configs[2]
+        # the configuration named for the 8-GPU run (fan-out 10,10): a short fetch-only measurement next to the weak-scaling
+        # value above (which keeps the N=1 fan-out so that the driver's per-N values are comparable)
+        if world > 1 and args.fanout == "5,5" and "error" not in (epoch or {}):
+            try:
+                extra = run_fanout_leg(args, comm, graph, table, device, [10, 10], backend, cold_partitioned, world, rank,
+                                       train_ids, steps_per_epoch, single_dev)
+            except Exception as e:  # noqa: BLE001
+                log(f"fan-out 10,10 leg failed: {e!r}")
+                extra = {"error": repr(e)}
+            if rank == 0:
+                line["config_fanout_10_10"] = extra
+        if watchdog is not None:
+            watchdog.cancel()
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
@@ -374,6 +386,49 @@ def main():
     del manager
     if world > 1:
         comm.destroy_process_group()
+
+
+def run_fanout_leg(args, comm, graph, table, device, fanout, backend, cold_partitioned, world, rank, train_ids, steps_per_epoch,
+                   single_dev, prewarm=150, steps=60):
+    """Fetch-only rate of the same table / graph / cache size at another fan-out (own cache handle, own sampler)."""
+    from COALA_GNN.COALA_GNN_Manager import COALA_GNN_Manager
+    from COALA_GNN.sampler import NeighborSampler
+    smp = NeighborSampler(fanout, seed=args.seed)
+    mgr = COALA_GNN_Manager(node_distributor=None, num_ssds=1, page_size=args.dim * 4, num_elems=1024, ssd_read_offset=0,
+                            cache_size=args.cache_mb, batch_size=args.batch, fan_out=fanout, dim=args.dim,
+                            MPI_comm_manager=comm, device=device, cache_backend=backend, sim_buf=table, num_rows=args.rows,
+                            cold_partitioned=cold_partitioned, exchange=args.exchange)
+    mgr.sync_on_return = False
+
+    def ids_for(step):
+        lo = ((step % max(steps_per_epoch, 1)) * world + rank) * args.batch
+        return smp.sample(graph, train_ids[lo: lo + args.batch].to(device))[0]
+    for s_ in range(prewarm):
+        mgr.fetch_feature((ids_for(s_),))
+    batches = [ids_for(prewarm + s_) for s_ in range(steps)]
+    torch.cuda.synchronize()
+    mgr.COALA_GNN_Cache.stats(reset=True)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rows = 0
+    for b in batches:
+        rows += mgr.fetch_feature((b,))[-1].shape[0]
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    hit, miss, _ = mgr.COALA_GNN_Cache.stats()
+    t = torch.tensor([dt, float(rows), float(hit), float(miss)], dtype=torch.float64, device="cpu" if single_dev else device)
+    tmax = t.clone()
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    dt = float(tmax[0])
+    del mgr
+    return {"workload": f"same table and cache, GraphSAGE fan-out {','.join(map(str, fanout))} bs={args.batch} (BASELINE.json configs[2])",
+            "value": round(float(t[1]) * args.dim * 4 / dt / 1e9, 3), "unit": "GB/s", "steps": steps, "prewarm_steps": prewarm,
+            "ms_per_step": round(dt / steps * 1e3, 4), "rows_per_step_per_gpu": round(float(t[1]) / world / steps, 1),
+            "hit_ratio": round(float(t[2]) / max(float(t[2] + t[3]), 1.0), 4)}
 
 
 def run_epoch_leg(args, comm, graph, sampler, table, device, fanout, steps_per_epoch, backend="isolated", cold_partitioned=False,

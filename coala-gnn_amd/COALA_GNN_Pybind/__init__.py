@@ -256,6 +256,14 @@ class _CacheBase:
     def _serve(self, out_ptr, ids_ptr, n):
         check(_lib.coala_cache_serve(self._h, int(out_ptr), int(ids_ptr), int(n), current_stream()))
 
+    def serve_probe(self, out_ptr, ids_ptr, n):
+        """First phase of a split serve: classify the whole batch, copy the hits (coala_cache_serve_probe)."""
+        check(_lib.coala_cache_serve_probe(self._h, int(out_ptr), int(ids_ptr), int(n), current_stream()))
+
+    def serve_fill(self, out_ptr, ids_ptr, n, begin, end):
+        """Second phase: cold fill of batch positions [begin, end) (coala_cache_serve_fill)."""
+        check(_lib.coala_cache_serve_fill(self._h, int(out_ptr), int(ids_ptr), int(n), int(begin), int(end), current_stream()))
+
     def route(self, idx_ptr, n, n_parts, node_ptr, map_ptr, counts_ptr, offsets_ptr=0, bucket_stride=0):
         check(_lib.coala_cache_route(self._h, int(idx_ptr), int(n), int(n_parts), int(bucket_stride), int(node_ptr),
                                      int(map_ptr), int(counts_ptr), int(offsets_ptr) or None, current_stream()))

@@ -44,6 +44,8 @@ SYMBOLS = {
     "coala_cache_geometry": (_I, [_VP, C.POINTER(CacheGeometry)]),
     "coala_cache_read_feature": (_I, [_VP, _VP, _VP, _I64, _VP]),
     "coala_cache_serve": (_I, [_VP, _VP, _VP, _I64, _VP]),
+    "coala_cache_serve_probe": (_I, [_VP, _VP, _VP, _I64, _VP]),
+    "coala_cache_serve_fill": (_I, [_VP, _VP, _VP, _I64, _I64, _I64, _VP]),
     "coala_cache_route": (_I, [_VP, _VP, _I64, _I, _I64, _VP, _VP, _VP, _VP, _VP]),
     "coala_cache_scatter": (_I, [_VP, _VP, _VP, _VP, _I64, _VP]),
     "coala_cache_row_dim": (_I64, [_VP]),

@@ -273,7 +273,8 @@ __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src) {
 
 template <int CD, int VEC, int NP = 4>
 __global__ __launch_bounds__(256) void miss_fill_kernel(CacheDev c, const int64_t* __restrict__ idx, float* __restrict__ out,
-                                                        int64_t n, int tile_rows) {
+                                                        int64_t n, int tile_rows, int64_t begin, int64_t end) {
+    // Works on batch positions [begin, end) (the whole batch, or one slice of a serve split into several fills).
     // A wave reads the verdicts of tile_rows rows at once (one byte per lane; tile_rows = R or 64) and then works through
     // the tile chunk by chunk (R rows), skipping chunks without a miss on a scalar mask.  With tile_rows = R this is one
     // verdict load per chunk: fine when the grid is wide (HBM cold tier).  Behind the 16..64-block grid of the host tier it
@@ -284,7 +285,8 @@ __global__ __launch_bounds__(256) void miss_fill_kernel(CacheDev c, const int64_
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
-    const int64_t n_tiles = (n + tile_rows - 1) / tile_rows;
+    const int64_t tile_first = begin / tile_rows;
+    const int64_t n_tiles = (end + tile_rows - 1) / tile_rows; // one past the last tile
     const int chunks_per_tile = tile_rows / R;
     const uint32_t nunits = c.dim / VEC;
     const int sub = (G::RPP == 2) ? (lane >> 5) : 0;
@@ -292,12 +294,12 @@ __global__ __launch_bounds__(256) void miss_fill_kernel(CacheDev c, const int64_
     uint32_t my_miss = 0, my_bad = 0;
 
     constexpr int U = 4; // verdict loads in flight per wave: the scan of a batch without misses is a chain of load latencies
-    for (int64_t tile0 = wave; tile0 < n_tiles; tile0 += n_waves * U) {
+    for (int64_t tile0 = tile_first + wave; tile0 < n_tiles; tile0 += n_waves * U) {
       uint32_t st_pack = 0; // the U verdict bytes of this lane, one per tile
 #pragma unroll
       for (int u = 0; u < U; ++u) {
           const int64_t p = (tile0 + u * n_waves) * tile_rows + lane;
-          const uint8_t v = (tile0 + u * n_waves < n_tiles && lane < tile_rows && p < n) ? c.row_state[p] : (uint8_t)0;
+          const uint8_t v = (tile0 + u * n_waves < n_tiles && lane < tile_rows && p >= begin && p < end) ? c.row_state[p] : (uint8_t)0;
           st_pack |= (uint32_t)v << (8 * u);
       }
       if (!__ballot(st_pack != 0)) continue; // nothing but hits in these U tiles
@@ -564,6 +566,7 @@ struct coala_cache {
                                           // fill took 1.8 ms instead of 0.22 ms, and the prefetching epoch 11.7 s instead of 9.2 s.
                                           // Full grid: 53.7 GB/s; 8 blocks: 43.1 GB/s.  COALA_K2_GRID overrides.
     int32_t* color_pin = nullptr;         // pinned staging for coala_cache_color_counts
+    int64_t open_batch_rows = -1;         // rows of a batch that was probed (serve_probe) and still waits for its fills
     int k2_tile_rows = 0;                 // rows per verdict tile of K2: 64 for a host cold tier, 0 = one chunk (COALA_K2_TILE_ROWS)
     int k1_passes = 4;                    // rows(-pairs) in flight per wave in K1 (tunable: COALA_K1_PASSES = 2 | 4)
     int k1_grid_cap = 256 * 8;            // K1 blocks (tunable: COALA_K1_GRID)
@@ -812,18 +815,29 @@ int coala_cache_geometry(const coala_cache_t* h, coala_cache_geometry_t* out) {
     return COALA_OK;
 }
 
-static int read_feature_impl(coala_cache_t* h, float* out, const int64_t* idx, int64_t n, void* stream, bool force_dist) {
+enum { kPhaseProbe = 1, kPhaseFill = 2, kPhaseBoth = 3 };
+
+static int read_feature_impl(coala_cache_t* h, float* out, const int64_t* idx, int64_t n, void* stream, bool force_dist,
+                             int phases = kPhaseBoth, int64_t begin = 0, int64_t end = -1) {
     if (!h) return fail(COALA_EINVAL, "null handle");
     if (n < 0 || n > 0x7FFFFFFFll) return fail(COALA_EINVAL, "n=%lld out of range", (long long)n);
     if (n == 0) return COALA_OK;
     if (!out || !idx) return fail(COALA_EINVAL, "null buffer");
+    if (end < 0) end = n;
+    if (begin < 0 || begin > end || end > n) return fail(COALA_EINVAL, "fill range [%lld, %lld) outside the batch of %lld rows", (long long)begin, (long long)end, (long long)n);
+    if (!(phases & kPhaseProbe) && (h->open_batch_rows != n || h->gen == 0))
+        return fail(COALA_EINVAL, "serve_fill without a matching serve_probe (batch of %lld rows, probe saw %lld)", (long long)n, (long long)h->open_batch_rows);
+    if (begin == end && !(phases & kPhaseProbe)) return COALA_OK;
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipSetDevice(h->cfg.device));
     int rc = ensure_scratch(h, (uint64_t)n, s);
     if (rc) return rc;
-    if (++h->gen == 0) { // generation wrapped: clear the chain heads once
-        HIPCHK(hipMemsetAsync(h->d.set_head, 0, h->d.num_sets * 8, s));
-        h->gen = 1;
+    if (phases & kPhaseProbe) {
+        if (++h->gen == 0) { // generation wrapped: clear the chain heads once
+            HIPCHK(hipMemsetAsync(h->d.set_head, 0, h->d.num_sets * 8, s));
+            h->gen = 1;
+        }
+        h->open_batch_rows = (phases & kPhaseFill) ? -1 : n; // a probe alone leaves the batch open for its fills
     }
     const uint32_t gen = h->gen;
     const bool vec4 = (h->d.dim % 4 == 0) && aligned16(out) && aligned16(h->d.cold);
@@ -835,7 +849,7 @@ static int read_feature_impl(coala_cache_t* h, float* out, const int64_t* idx, i
         using G = Geo<CD, VEC>;
         const int64_t chunks = (n + G::R - 1) / G::R;
         // K1: 2-wave blocks, every wave resident; grid-stride over the chunks
-        {
+        if (phases & kPhaseProbe) {
             ProfScope ps(h, s, 0, (uint64_t)n);
             const bool full = (VEC == 4) && ((int)d.dim == CD);
             if (h->k1_passes == 2) {
@@ -851,14 +865,15 @@ static int read_feature_impl(coala_cache_t* h, float* out, const int64_t* idx, i
                                    dim3(64 * kK1Waves), 0, s, d, idx, out, n, gen);
             }
         }
-        {
+        if ((phases & kPhaseFill) && end > begin) {
             ProfScope ps(h, s, 2, 0);
             // verdict tile: 64 rows behind the narrow host-tier grid, one chunk behind the wide HBM-tier grid (see the kernel)
             const int tile_rows = h->k2_tile_rows > 0 ? h->k2_tile_rows : G::R;
-            hipLaunchKernelGGL((miss_fill_kernel<CD, VEC>), dim3(grid_for((n + tile_rows - 1) / tile_rows, 4, h->k2_grid_cap)), dim3(256), 0,
-                               s, d, idx, out, n, tile_rows);
+            const int64_t tiles = (end + tile_rows - 1) / tile_rows - begin / tile_rows;
+            hipLaunchKernelGGL((miss_fill_kernel<CD, VEC>), dim3(grid_for(tiles, 4, h->k2_grid_cap)), dim3(256), 0,
+                               s, d, idx, out, n, tile_rows, begin, end);
         }
-        h->rows_total += (uint64_t)n;
+        if (phases & kPhaseProbe) h->rows_total += (uint64_t)n;
         return COALA_OK;
     });
     if (rc) return rc;
@@ -873,6 +888,14 @@ int coala_cache_read_feature(coala_cache_t* h, float* out, const int64_t* idx, i
 
 int coala_cache_serve(coala_cache_t* h, float* out, const int64_t* ids, int64_t n, void* stream) {
     return read_feature_impl(h, out, ids, n, stream, true);
+}
+
+int coala_cache_serve_probe(coala_cache_t* h, float* out, const int64_t* ids, int64_t n, void* stream) {
+    return read_feature_impl(h, out, ids, n, stream, true, kPhaseProbe);
+}
+
+int coala_cache_serve_fill(coala_cache_t* h, float* out, const int64_t* ids, int64_t n, int64_t begin, int64_t end, void* stream) {
+    return read_feature_impl(h, out, ids, n, stream, true, kPhaseFill, begin, end);
 }
 
 int coala_cache_route(coala_cache_t* h, const int64_t* idx, int64_t n, int n_parts, int64_t bucket_stride,

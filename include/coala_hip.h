@@ -102,6 +102,14 @@ int coala_cache_read_feature(coala_cache_t* h, float* out, const int64_t* idx, i
  * this owner; out = packed fp32 [n, dim] in the same order. */
 int coala_cache_serve(coala_cache_t* h, float* out, const int64_t* ids, int64_t n, void* stream);
 
+/* The same serve in two phases, for callers that overlap the cold fill with the exchange of rows that are already in place
+ * (ssd_gnn_cache.cuh:132-174 serves and ships peer by peer on separate streams): serve_probe classifies the WHOLE batch and
+ * copies the hits; serve_fill completes the positions [begin, end) -- ranking still spans the whole batch, so any set of
+ * fills that covers [0, n) once, in any order, leaves table, counters and rows exactly as one coala_cache_serve does.
+ * Same out / ids / n in every call of one batch; the next probe starts the next batch. */
+int coala_cache_serve_probe(coala_cache_t* h, float* out, const int64_t* ids, int64_t n, void* stream);
+int coala_cache_serve_fill(coala_cache_t* h, float* out, const int64_t* ids, int64_t n, int64_t begin, int64_t end, void* stream);
+
 /* Bucket idx by owner = id % n_parts, stable inside each bucket.  Replaces Isolated_Cache::split_node_list
  * (ssd_gnn_cache.cuh:283-295) / nccl_split_node_list_kernel (cache_kernel.cu:79-91) and the routing half of
  * NVSHMEM_send_requests_kernel (cache_kernel.cu:4-17).

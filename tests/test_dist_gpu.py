@@ -186,3 +186,49 @@ def test_reference_call_sequence_nccl_helpers(hiplib, oracle):
     for c in caches:
         c.close()
     table.close()
+
+
+@pytest.mark.parametrize("dim,tier", [(1024, "host"), (128, "host"), (300, "hbm")])
+def test_split_serve_equals_one_serve(hiplib, oracle, dim, tier, monkeypatch):
+    """coala_cache_serve_probe + coala_cache_serve_fill over slices that cover the batch once, in any order, leave rows, tag
+    table, cursors and counters exactly as one coala_cache_serve (and as the oracle): ranking spans the whole batch."""
+    import torch
+    P = hiplib
+    rng = np.random.default_rng(11)
+    num_rows, G = 20000, 2
+    feat = oracle.make_features(num_rows, dim, seed=9)
+    owned = np.arange(0, num_rows, G)                       # owner 0 serves ids = 0 (mod G)
+    table = PinnedTable(P, feat) if tier == "host" else None
+    dev_table = torch.from_numpy(feat).cuda() if tier == "hbm" else None
+    ptr = table.device_ptr if table is not None else dev_table.data_ptr()
+    ctrl = P.SSD_GNN_SSD_Controllers(1, 4096, 1024, 0, 0, dim, True)
+    a = P.SSD_GNN_NVSHMEM_Cache(ctrl, None, 0, G, 1, ptr, num_rows=num_rows, rank=0)
+    b = P.SSD_GNN_NVSHMEM_Cache(ctrl, None, 0, G, 1, ptr, num_rows=num_rows, rank=0)
+    orc = oracle.OracleCache(1, dim, feat, n_gpus=G, distributed=True)
+    with pytest.raises(RuntimeError):                        # a fill needs its probe
+        b.serve_fill(0, 0, 5, 0, 5)
+    for step in range(6):
+        n = int(rng.integers(1, 4000))
+        ids = rng.choice(owned, size=n, replace=step % 2 == 0).astype(np.int64)   # duplicates every other step
+        d_ids = torch.from_numpy(ids).cuda()
+        out_a = torch.full((n, dim), -1.0, device="cuda")
+        out_b = torch.full((n, dim), -1.0, device="cuda")
+        a.serve(out_a.data_ptr(), d_ids.data_ptr(), n)
+        cuts = sorted({0, n, *(int(c) for c in rng.integers(0, n + 1, size=3))})
+        slices = list(zip(cuts[:-1], cuts[1:]))
+        rng.shuffle(slices)
+        b.serve_probe(out_b.data_ptr(), d_ids.data_ptr(), n)
+        for lo, hi in slices:
+            b.serve_fill(out_b.data_ptr(), d_ids.data_ptr(), n, lo, hi)
+        orc.read_feature(ids, oracle.SCHED_HITS_FIRST, want_rows=False)
+        torch.cuda.synchronize()
+        assert out_b.cpu().numpy().tobytes() == feat[ids].tobytes() and torch.equal(out_a, out_b), f"step {step}"
+        assert a.stats() == b.stats() == (orc.hit_cnt, orc.miss_cnt, 0)
+        for x, y in zip(a.dump(), b.dump()):
+            assert np.array_equal(x, y)
+        assert np.array_equal(b.dump()[0], orc.keys()) and np.array_equal(b.dump()[1], orc.set_cnt())
+    with pytest.raises(RuntimeError):                        # wrong batch size for the open batch
+        b.serve_fill(out_b.data_ptr(), d_ids.data_ptr(), n + 1, 0, 1)
+    a.close(); b.close()
+    if table is not None:
+        table.close()

@@ -566,6 +566,12 @@ def run_cpu_baseline(args, host_array, batches, fanout, graph=None, seeds_for=No
         for s in range(k):
             O.sample_blocks(ip, ix, seeds_for(s).cpu().numpy(), list(reversed(fanout)), args.seed, s)
         res["sampler_twin_one_core_ms_per_minibatch"] = round((time.perf_counter() - t0) / k * 1e3, 3)
+    # extrapolated epoch of the CPU path = steps x (CPU sampler + best CPU gather), no training step
+    steps_per_epoch = int(0.6 * args.rows) // args.batch - 1
+    ms_oracle = dt / max(i, 1) * 1e3
+    ms_gather = min(ms_oracle, res["index_select_all_cores"].get("ms_per_minibatch", ms_oracle))
+    res["epoch_time_s_extrapolated_sampler_plus_gather"] = round(
+        steps_per_epoch * (ms_gather + res.get("sampler_twin_one_core_ms_per_minibatch", 0.0)) / 1e3, 1)
     return res
 
 

@@ -136,6 +136,8 @@ class COALA_GNN_DataLoader(torch.utils.data.DataLoader):
             cache_backend=cache_backend, sim_buf=sim_buf, num_rows=num_rows, profile=profile,
             cold_partitioned=cold_partitioned, out_ring=self.prefetch + 2)  # batches alive at once: consumer + queue + producer
         self.COALA_GNN_Manager.sync_on_return = bool(sync_fetch)
+        # the native sampler is stream-aware (it launches on torch's current stream); a foreign sampler keeps the caller's stream
+        self._sample_on_side_stream = (not sync_fetch) and str(device).startswith("cuda") and getattr(graph_sampler, "stream_safe", False)
         self.scheduler = COALA_GNN_Node_Distribution_Scheduler(node_distributor=self.node_distributor,
                                                                ssd_gnn_manager=self.COALA_GNN_Manager,
                                                                refresh_counter=self.refresh_counter)
@@ -156,8 +158,23 @@ class COALA_GNN_DataLoader(torch.utils.data.DataLoader):
         # last step of the epoch: do not launch a distributor thread past the end of the id list (the
         # reference's is_last test compares a step counter with the id count and never fires)
         is_last_iter = self.counter + 1 >= self.total_count
-        distributed_index = self.scheduler.run(is_last_iter).to(self.device)
-        batch = self.sampler.sample(self.g, distributed_index)
+        seeds = self.scheduler.run(is_last_iter)
+        if not self._sample_on_side_stream:
+            batch = self.sampler.sample(self.g, seeds.to(self.device))
+        else:
+            # Same order of work as the reference's __next__, one host thread -- but the sampler's kernels (and the seed copy)
+            # go to their own stream: they depend on nothing the training step of the previous iteration does, and on the
+            # caller's stream the host read-back at the end of the sampler would wait for that whole step to drain.
+            cur = torch.cuda.current_stream()
+            if self._sample_stream is None:
+                self._sample_stream = torch.cuda.Stream(device=self.device)
+            with torch.cuda.stream(self._sample_stream):
+                batch = self.sampler.sample(self.g, seeds.to(self.device))
+                ev = torch.cuda.Event()
+                ev.record()
+            cur.wait_event(ev)
+            for t in _device_tensors(batch):
+                t.record_stream(cur)  # allocated on the sampler's stream, used by fetch and training on this one
         self.counter += 1
         return self.COALA_GNN_Manager.fetch_feature(batch)
 

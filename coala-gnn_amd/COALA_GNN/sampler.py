@@ -89,6 +89,8 @@ class Block(object):
 
 
 class NeighborSampler(object):
+    stream_safe = True  # every kernel and allocation of sample() goes to torch's current stream
+
     def __init__(self, fanouts, seed=0):
         self.fanouts = [int(f) for f in fanouts]
         if not 1 <= len(self.fanouts) <= 8:

@@ -58,7 +58,7 @@ def parse_args():
     ap.add_argument("--epoch-prefetch-multi", action="store_true",
                     help="N>1: also run the epoch leg with the prefetching loader (the exchange's RCCL communicator and DDP's are then "
                          "driven from two host threads; not validated on multi-GPU hardware yet, hence opt-in)")
-    ap.add_argument("--epoch-timeout", type=float, default=420.0,
+    ap.add_argument("--epoch-timeout", type=float, default=180.0,
                     help="N>1: seconds after which the epoch leg is abandoned and the JSON line printed without it")
     ap.add_argument("--exchange", type=str, default=None, choices=["torch", "native"],
                     help="N>1: torch.distributed all_to_all_single (default) or the fused native RCCL call")

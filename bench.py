@@ -467,8 +467,11 @@ def run_epoch_leg(args, comm, graph, sampler, table, device, fanout, steps_per_e
         np.save(files[0], color); np.save(files[1], tk); np.save(files[2], sc)
         del color
         n_train = int(0.6 * args.rows)
-        full = args.epoch_steps < 0
-        need = n_train if full else (args.epoch_steps * 2 + 260) * args.batch * world
+        epoch_steps = args.epoch_steps
+        if world > 1 and epoch_steps < 0 and steps_per_epoch > 1500:
+            epoch_steps = 1000  # N = 2: bound the leg (and stay far from the watchdog); N = 4, 8 measure the whole epoch
+        full = epoch_steps < 0
+        need = n_train if full else (epoch_steps * 2 + 260) * args.batch * world
         train_ids = torch.randperm(n_train, generator=torch.Generator().manual_seed(1))[: min(n_train, need)]
         graph.ndata["labels"] = (torch.arange(args.rows, device=device) * 7) % 19
         for name, prefetch in modes:
@@ -496,7 +499,7 @@ def run_epoch_leg(args, comm, graph, sampler, table, device, fanout, steps_per_e
                 del loader, nd
                 continue
             train_steps(loader, model, opt, 100, device)                       # warm the cache and the allocator
-            steps, secs, nodes = train_steps(loader, model, opt, args.epoch_steps, device)
+            steps, secs, nodes = train_steps(loader, model, opt, epoch_steps, device)
             secs, nodes = across_ranks(secs, nodes)
             ms = secs / max(steps, 1) * 1e3
             out[name] = {"steps": steps, "ms_per_step": round(ms, 3), "epoch_time_s_extrapolated": round(ms * steps_per_epoch / 1e3, 2),

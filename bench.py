@@ -214,6 +214,10 @@ def main():
     torch.cuda.synchronize()
     cache.stats(reset=True)
     cache.profile(reset=True)
+    xch = manager.exchange if world > 1 and hasattr(manager.exchange, "reset_profile") else None
+    if xch is not None:
+        xch.reset_profile()
+        xch.profile = True
 
     # ---------------------------------------------------------------- timed region
     if world > 1:
@@ -243,6 +247,27 @@ def main():
         rows_all, hit_all, miss_all = float(stat[1]), float(stat[2]), float(stat[3])
     else:
         rows_all, hit_all, miss_all = float(rows_done), float(hit), float(miss)
+
+    # ---------------------------------------------------------------- N>1: the row exchange against the xGMI ceiling
+    # achieved_xGMI = remote bytes received / t_exchange per GPU; ceiling 153 GB/s per pair, (N-1) pairs per GPU
+    exchange_obj = None
+    if xch is not None:
+        xch.profile = False
+        ms, calls, remote_rows = xch.fold_profile()
+        e = torch.tensor([ms, float(calls), float(remote_rows)], dtype=torch.float64, device="cpu" if single_dev else device)
+        e_max = e.clone()
+        dist.all_reduce(e_max, op=dist.ReduceOp.MAX)
+        dist.all_reduce(e, op=dist.ReduceOp.SUM)
+        if float(e[1]) > 0:
+            avg_us = float(e[0]) / float(e[1]) * 1e3                       # mean over ranks and steps
+            bytes_in = float(e[2]) / float(e[1]) * args.dim * 4            # per GPU per step
+            ach = bytes_in / (avg_us * 1e-6) / 1e9 if avg_us > 0 else 0.0
+            peak = 153.0 * (world - 1)
+            exchange_obj = {"bound": "xgmi", "collective": "all-to-all-v of rows (RCCL)", "avg_us": round(avg_us, 2),
+                            "slowest_rank_avg_us": round(float(e_max[0]) / max(float(e_max[1]), 1.0) * 1e3, 2),
+                            "remote_bytes_in_per_gpu_per_step": int(bytes_in), "achieved": round(ach, 1), "peak": peak,
+                            "unit": "GB/s per GPU ingress", "frac": round(ach / peak, 4),
+                            "note": "HIP events around the row exchange on every rank; peak = 153 GB/s per peer link x (N-1) peers"}
 
     payload_bytes = rows_all * args.dim * 4
     value = payload_bytes / elapsed / 1e9
@@ -329,6 +354,7 @@ def main():
             "roofline": roofline,
             "roofline_allhit": roofline_allhit,
             "roofline_cold_fill": roofline_cold,
+            "exchange": exchange_obj,
             "epoch": None,
             "cpu_baseline": cpu_baseline,
         }

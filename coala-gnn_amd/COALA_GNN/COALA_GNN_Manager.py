@@ -70,6 +70,24 @@ class AllToAllExchange(object):
         self._both_host = torch.zeros((2, world), dtype=torch.int64, pin_memory=on_gpu)
         self.last_send_counts = None
         self.last_recv_counts = None
+        # profile = True brackets the row exchange with HIP events (bench.py's xGMI figure: BASELINE.md "achieved_xGMI")
+        self.profile = False
+        self._row_events = []
+        self.rows_a2a_ms = 0.0
+        self.rows_a2a_calls = 0
+        self.remote_rows_in = 0
+
+    def fold_profile(self):
+        """Finish the pending event pairs; -> (milliseconds in the row all-to-all-v, calls, rows received from other ranks)."""
+        for a, b in self._row_events:
+            b.synchronize()
+            self.rows_a2a_ms += a.elapsed_time(b)
+        self._row_events = []
+        return self.rows_a2a_ms, self.rows_a2a_calls, self.remote_rows_in
+
+    def reset_profile(self):
+        self.fold_profile()
+        self.rows_a2a_ms, self.rows_a2a_calls, self.remote_rows_in = 0.0, 0, 0
 
     def _a2a(self, out, inp, out_splits=None, in_splits=None):
         if self.world == 1:
@@ -109,7 +127,16 @@ class AllToAllExchange(object):
         rows_send = torch.empty((max(total_recv, 1), self.dim), dtype=torch.float32, device=dev)
         ops.serve(rows_send.data_ptr(), recv_ids.data_ptr(), total_recv)
         rows_recv = torch.empty((max(n, 1), self.dim), dtype=torch.float32, device=dev)
+        timed = self.profile and rows_recv.is_cuda
+        if timed:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         self._a2a(rows_recv[:n], rows_send[:total_recv], send_c, recv_c)
+        if timed:
+            ev[1].record()
+            self._row_events.append(ev)
+            self.rows_a2a_calls += 1
+            self.remote_rows_in += n - int(send_c[self.rank])
         ops.scatter(out_ptr, rows_recv.data_ptr(), mp.data_ptr(), n)
         self._keep = (rows_recv, mp)  # until the next step: scatter is stream-ordered, torch's allocator is too
 

@@ -45,5 +45,7 @@ def test_bench_two_ranks_on_one_gpu_with_epoch_leg():
     e = d["epoch"]
     assert "error" not in e and e["serial"]["steps"] == 12 and e["prefetch"]["steps"] == 12
     assert "DistributedDataParallel" in e["model"]
+    xg = d["exchange"]
+    assert xg["bound"] == "xgmi" and xg["avg_us"] > 0 and xg["remote_bytes_in_per_gpu_per_step"] > 0 and xg["peak"] == 153.0
     x = d["config_fanout_10_10"]
     assert "error" not in x and x["value"] > 0 and x["steps"] == 60 and 0 <= x["hit_ratio"] <= 1

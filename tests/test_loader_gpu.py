@@ -126,3 +126,47 @@ def test_example_training_script_runs():
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     assert out.stdout.count("Epoch Time:") == 2 and "GPU hit ratio:" in out.stdout and "Aggregation time:" in out.stdout
     assert "final loss" in out.stdout
+
+
+def test_loader_modes_are_equivalent(hiplib, oracle, tmp_path):
+    """The reference's blocking __next__ (sync_fetch=True), the stream-ordered default and the prefetching producer deliver the
+    same batches in the same order and leave the same tag table, cursors and counters: they differ in scheduling only."""
+    import torch
+    from COALA_GNN import COALA_GNN_DataLoader, MPI_Comm_Manager, Node_Distributor, SSD_INFO
+    from COALA_GNN.sampler import NeighborSampler
+    from COALA_GNN.synthetic import alloc_pinned_table, block_colors, powerlaw_csc
+    n_nodes, dim, batch, fan = 30000, 256, 128, [5, 5]
+    table = alloc_pinned_table(n_nodes, dim, seed=7, device=0)
+    indptr, indices = powerlaw_csc(n_nodes, 8.0, seed=2, device="cuda")
+    color, tk, sc, ncol = block_colors(n_nodes, nodes_per_color=512)
+    files = ColorFiles(tmp_path, color, tk, sc)
+    comm = MPI_Comm_Manager(0)
+    comm.initialize_nested_process_group("isolated")
+    train_ids = torch.randperm(int(0.6 * n_nodes), generator=torch.Generator().manual_seed(3))[:batch * 25]
+    results = []
+    for kw in ({"sync_fetch": True}, {}, {"prefetch": 2}):
+        nd = Node_Distributor(comm, train_ids, batch, files.color_file, files.topk_file, files.score_file, parsing_method="node_color")
+        sampler = NeighborSampler(fan, seed=9)
+        g = sampler.make_graph(indptr, indices)
+        loader = COALA_GNN_DataLoader(SSD_INFO(1, dim * 4, 1024, 0), nd, g, sampler, batch, dim, fan, 2, "cuda:0", refresh_counter=4,
+                                      cache_backend="isolated", sim_buf=table, num_rows=n_nodes, **kw)
+        seen = []
+        for input_nodes, seeds, blocks, feat in loader:
+            # a consumer that only uses the stream contract: work ordered on the current stream
+            seen.append((input_nodes.clone(), seeds.clone(), feat.sum(dim=1), blocks[0].nbr.clone()))
+        torch.cuda.synchronize()
+        cache = loader.COALA_GNN_Manager.COALA_GNN_Cache
+        cc = np.zeros(ncol + 1, dtype=np.int32)
+        cache.get_cache_data(cc.ctypes.data, ncol + 1)
+        results.append((seen, cache.stats(), cache.dump(), cc, loader.COALA_GNN_Manager.get_aggregate_time()))
+        del loader, nd
+    ref = results[0]
+    assert len(ref[0]) == 24 and ref[4] > 0
+    for other in results[1:]:
+        assert len(other[0]) == len(ref[0]) and other[1] == ref[1] and other[4] > 0
+        for (a_in, a_seed, a_sum, a_nbr), (b_in, b_seed, b_sum, b_nbr) in zip(ref[0], other[0]):
+            assert torch.equal(a_in, b_in) and torch.equal(a_seed, b_seed) and torch.equal(a_sum, b_sum) and torch.equal(a_nbr, b_nbr)
+        for x, y in zip(ref[2], other[2]):
+            assert np.array_equal(x, y)
+        assert np.array_equal(ref[3], other[3])
+    table.close()

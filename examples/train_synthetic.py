@@ -102,7 +102,7 @@ def main():
         print(f"Total number of iterations: {count}")
         print(f"Number of sampled nodes : {num_sampled_nodes}")
         train_loader.print_stats()
-    print(f"final loss {float(loss):.4f}")
+    print(f"final loss {loss.item():.4f}")
     comm.global_comm.Barrier()
     del train_loader
     comm.destroy_process_group()

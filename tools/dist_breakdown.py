@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Timing of the owner-partitioned path's device pieces on ONE GPU (development tool): route, serve, scatter."""
-import os, sys, time
+import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "coala-gnn_amd"))
 import torch

@@ -6,7 +6,6 @@ from COALA_GNN import MPI_Comm_Manager, Node_Distributor, SSD_INFO, COALA_GNN_Da
 from COALA_GNN.harness import SageMean
 from COALA_GNN.sampler import NeighborSampler
 from COALA_GNN.synthetic import alloc_pinned_table, block_colors, powerlaw_csc
-import COALA_GNN.COALA_GNN_DataLoader as DL
 import sys as _s
 _s.setswitchinterval(float(os.environ.get("SWITCH", "0.005")))
 rows, dim, batch, fan = 10_000_000, 1024, 1024, [5, 5]

@@ -253,7 +253,11 @@ def main():
     exchange_obj = None
     if xch is not None:
         xch.profile = False
-        ms, calls, remote_rows = xch.fold_profile()
+        try:
+            ms, calls, remote_rows = xch.fold_profile()
+        except Exception as e:  # noqa: BLE001 -- diagnostics must never cost the headline number
+            log(f"exchange timing unavailable: {e!r}")
+            ms, calls, remote_rows = 0.0, 0, 0
         e = torch.tensor([ms, float(calls), float(remote_rows)], dtype=torch.float64, device="cpu" if single_dev else device)
         e_max = e.clone()
         dist.all_reduce(e_max, op=dist.ReduceOp.MAX)

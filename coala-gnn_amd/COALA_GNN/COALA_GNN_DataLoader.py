@@ -119,6 +119,7 @@ class COALA_GNN_DataLoader(torch.utils.data.DataLoader):
         self._queue = None
         self._side_stream = None
         self._sample_stream = None
+        self._stop = threading.Event()   # set by close(): the producer gives up at its next queue hand-off
         self.producer_times = {"schedule": 0.0, "sample": 0.0, "fetch": 0.0, "queue_full": 0.0, "gpu_backlog": 0.0}
         self.refresh_counter = refresh_counter
         self.sampler = graph_sampler
@@ -236,12 +237,36 @@ class COALA_GNN_DataLoader(torch.utils.data.DataLoader):
                 T["fetch"] += clock() - t0
                 nxt = sample_next() if self.counter < self.total_count else None  # overlaps the fetch just enqueued
                 t0 = clock()
-                self._queue.put((item, ev_f))
+                if not self._hand_over((item, ev_f)):
+                    break  # the loader is being closed mid-epoch
                 T["queue_full"] += clock() - t0
             mgr.sync_on_return = keep_sync
-            self._queue.put(None)
+            self._hand_over(None)
         except BaseException as e:  # surface producer failures in the consumer
-            self._queue.put(e)
+            self._hand_over(e)
+
+    def _hand_over(self, obj):
+        """queue.put that a close() can interrupt (a consumer that left the loop early never empties the queue)."""
+        while not self._stop.is_set():
+            try:
+                self._queue.put(obj, timeout=0.05)
+                return True
+            except queue.Full:
+                continue
+        return False
+
+    def close(self):
+        """Stop a prefetching producer (if any) and the scheduler's helpers; safe to call twice, also mid-epoch."""
+        self._stop.set()
+        if self._producer is not None:
+            try:
+                while True:  # let a producer blocked on a full queue see the flag
+                    self._queue.get_nowait()
+            except queue.Empty:
+                pass
+            self._producer.join(timeout=10)
+            self._producer = None
+        self.scheduler.drain()
 
     def __next__(self):  # COALA_GNN_DataLoader.py:149-167
         if self.prefetch <= 0:
@@ -258,6 +283,7 @@ class COALA_GNN_DataLoader(torch.utils.data.DataLoader):
                 # 0.3 ms under a training load but leaves the epoch time unchanged -- the fetch, not the sampler, is the limit)
                 self._side_stream = torch.cuda.Stream(device=self.device)
                 self._sample_stream = torch.cuda.Stream(device=self.device)
+            self._stop.clear()
             self._producer = threading.Thread(target=self._producer_loop, daemon=True)
             self._producer.start()
         got = self._queue.get()
@@ -286,9 +312,7 @@ class COALA_GNN_DataLoader(torch.utils.data.DataLoader):
 
     def __del__(self):
         try:
-            if self._producer is not None:
-                self._producer.join(timeout=30)
-            self.scheduler.drain()
+            self.close()
             del self.COALA_GNN_Manager
         except Exception:
             pass

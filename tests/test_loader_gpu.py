@@ -170,3 +170,38 @@ def test_loader_modes_are_equivalent(hiplib, oracle, tmp_path):
             assert np.array_equal(x, y)
         assert np.array_equal(ref[3], other[3])
     table.close()
+
+
+def test_prefetching_loader_can_be_abandoned_mid_epoch(hiplib, oracle, tmp_path):
+    """A consumer that leaves the loop early must not leave the producer thread blocked on its queue: close() (or dropping the
+    loader) returns promptly and the process can go on using the GPU."""
+    import time
+    import torch
+    from COALA_GNN import COALA_GNN_DataLoader, MPI_Comm_Manager, Node_Distributor, SSD_INFO
+    from COALA_GNN.sampler import NeighborSampler
+    from COALA_GNN.synthetic import alloc_pinned_table, block_colors, powerlaw_csc
+    n_nodes, dim, batch, fan = 20000, 128, 64, [5, 5]
+    table = alloc_pinned_table(n_nodes, dim, seed=3, device=0)
+    indptr, indices = powerlaw_csc(n_nodes, 8.0, seed=1, device="cuda")
+    color, tk, sc, _ = block_colors(n_nodes, nodes_per_color=512)
+    files = ColorFiles(tmp_path, color, tk, sc)
+    comm = MPI_Comm_Manager(0)
+    comm.initialize_nested_process_group("isolated")
+    train_ids = torch.randperm(int(0.6 * n_nodes), generator=torch.Generator().manual_seed(0))[:64 * 40]
+    nd = Node_Distributor(comm, train_ids, batch, files.color_file, files.topk_file, files.score_file, parsing_method="baseline")
+    sampler = NeighborSampler(fan, seed=5)
+    g = sampler.make_graph(indptr, indices)
+    loader = COALA_GNN_DataLoader(SSD_INFO(1, dim * 4, 1024, 0), nd, g, sampler, batch, dim, fan, 4, "cuda:0",
+                                  cache_backend="isolated", sim_buf=table, num_rows=n_nodes, prefetch=2)
+    for step, (input_nodes, seeds, blocks, feat) in enumerate(loader):
+        if step == 3:
+            break
+    time.sleep(0.3)                      # the producer has filled its queue and is waiting
+    producer = loader._producer
+    assert producer is not None and producer.is_alive()
+    t0 = time.time()
+    loader.close()
+    assert time.time() - t0 < 5.0 and not producer.is_alive()
+    del loader
+    torch.cuda.synchronize()
+    table.close()

@@ -24,21 +24,20 @@ __all__ = ["COALA_GNN_Manager", "NVShmem_Tensor_Manager", "AllToAllExchange", "N
 
 
 class NVShmem_Tensor_Manager(object):
-    """COALA_GNN_Manager.py:8-40.  Owns the per-step output buffer ring and the request buffer (plain HBM)."""
+    """COALA_GNN_Manager.py:8-40.  Hands out the per-step output tensor and owns the request buffer (plain HBM).
+
+    The reference returns a view of ONE symmetric buffer every step (:127-128): the tensor of step t is overwritten by the
+    fetch of step t+1.  Here every step gets its own tensor from torch's caching allocator, like the other backends: a
+    prefetching loader fetches step t+k on a side stream while the training kernels of step t still read their rows, and only
+    the allocator's stream bookkeeping (record_stream, done by the loader) makes that reuse safe -- a persistent ring is not."""
 
     def __init__(self, max_rows, dim, n_gpus, device, ring=2):
         self.device = device
         self.dim = dim
-        self.batch = [torch.empty((max_rows, dim), dtype=torch.float32, device=device) for _ in range(ring)]
         self.index_tensor = torch.empty((n_gpus, max_rows * 2), dtype=torch.int64, device=device)
-        self._turn = 0
 
     def get_batch_tensor(self, shape):
-        # ring of buffers: the tensor returned for step t stays valid while step t+1 is being fetched (the reference
-        # returns a view of ONE symmetric buffer every step, COALA_GNN_Manager.py:127-128)
-        buf = self.batch[self._turn]
-        self._turn = (self._turn + 1) % len(self.batch)
-        return buf[: shape[0]]
+        return torch.empty((int(shape[0]), self.dim), dtype=torch.float32, device=self.device)
 
     def get_index_tensor(self):
         return self.index_tensor
@@ -47,27 +46,41 @@ class NVShmem_Tensor_Manager(object):
         return self.index_tensor.data_ptr()
 
 
-class AllToAllExchange(object):
-    """ids out / rows back over one process group.  `ops` provides the device primitives as pointer-level calls
-    (route, serve, scatter): a COALA_GNN_Pybind cache object in the product; tests may inject another provider to
-    exercise this host logic with gloo on CPU tensors."""
+def _round_slices(cnt, dis, rounds, skip):
+    """[(begin, end)] per round: slice k of every peer's segment [dis[p], dis[p] + cnt[p]), peer `skip` left out."""
+    out = []
+    for k in range(rounds):
+        out.append([(dis[p] + cnt[p] * k // rounds, dis[p] + cnt[p] * (k + 1) // rounds) if p != skip else (dis[p], dis[p])
+                    for p in range(len(cnt))])
+    return out
 
-    def __init__(self, group, rank, world, dim, device, stage_through_host=None):
+
+class AllToAllExchange(object):
+    """ids out / rows back over one torch.distributed process group -- the same split-phase sequence as the native call
+    (coala_comm.cpp): route -> counts -> ONE host read -> ids -> probe (the requester's own shard goes straight into the
+    output tensor) -> per round { cold fill of slice k of every peer's segment | rows of slice k on a side stream } ->
+    un-permute per round.  `ops` provides the device primitives as pointer-level calls: a COALA_GNN_Pybind cache object in
+    the product; tests may inject another provider to exercise this host logic with gloo on CPU tensors."""
+
+    def __init__(self, group, rank, world, dim, device, stage_through_host=None, rounds=2):
         self.group, self.rank, self.world, self.dim, self.device = group, rank, world, dim, device
         # RCCL moves GPU tensors directly.  A gloo group cannot (no CUDA all-to-all): then the buffers are staged through
         # host memory -- transport only, used by the multi-process tests on a one-GPU box; the kernels stay on the GPU.
+        on_gpu = str(device).startswith("cuda")
         if stage_through_host is None:
-            stage_through_host = (world > 1 and str(device).startswith("cuda") and dist.is_initialized()
-                                  and dist.get_backend(group) == "gloo")
+            stage_through_host = (world > 1 and on_gpu and dist.is_initialized() and dist.get_backend(group) == "gloo")
         self.stage_through_host = bool(stage_through_host)
+        self.rounds = max(1, int(rounds))
         self._pending = None
         self.counts = torch.zeros(world, dtype=torch.int64, device=device)
         self.offsets = torch.zeros(world + 1, dtype=torch.int64, device=device)
         self.recv_counts = torch.zeros(world, dtype=torch.int64, device=device)
-        on_gpu = str(device).startswith("cuda")
         self._both_dev = torch.zeros((2, world), dtype=torch.int64, device=device)
         # pinned: a D2H copy into pageable memory is staged by the runtime and can wait on more than this stream
         self._both_host = torch.zeros((2, world), dtype=torch.int64, pin_memory=on_gpu)
+        # persistent workspaces, grown on demand (no per-step allocation)
+        self._ws = {}
+        self._side = torch.cuda.Stream(device=device) if (on_gpu and world > 1 and not self.stage_through_host) else None
         self.last_send_counts = None
         self.last_recv_counts = None
         # profile = True brackets the row exchange with HIP events (bench.py's xGMI figure: BASELINE.md "achieved_xGMI")
@@ -77,8 +90,17 @@ class AllToAllExchange(object):
         self.rows_a2a_calls = 0
         self.remote_rows_in = 0
 
+    def _buf(self, name, numel, dtype):
+        t = self._ws.get(name)
+        if t is None or t.numel() < numel:
+            if t is not None and t.is_cuda:
+                torch.cuda.current_stream().synchronize()  # kernels of the previous step may still use the old buffer
+            t = torch.empty(max(int(numel * 1.25), 1024), dtype=dtype, device=self.device)
+            self._ws[name] = t
+        return t
+
     def fold_profile(self):
-        """Finish the pending event pairs; -> (milliseconds in the row all-to-all-v, calls, rows received from other ranks)."""
+        """Finish the pending event pairs; -> (milliseconds in the row exchange, calls, rows received from other ranks)."""
         for a, b in self._row_events:
             b.synchronize()
             self.rows_a2a_ms += a.elapsed_time(b)
@@ -99,12 +121,26 @@ class AllToAllExchange(object):
         else:
             dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
 
+    def _a2a_slices(self, dst, dst_slices, src, src_slices):
+        """Every peer p receives src[src_slices[p]] and delivers into dst[dst_slices[p]] (rows; slices are (begin, end))."""
+        outs = [dst[b:e] for b, e in dst_slices]
+        ins = [src[b:e] for b, e in src_slices]
+        if self.stage_through_host or not dst.is_cuda:
+            h_in = torch.cat([t.cpu() for t in ins]) if ins else src[:0].cpu()
+            h_out = torch.empty((sum(t.shape[0] for t in outs),) + tuple(dst.shape[1:]), dtype=dst.dtype)
+            dist.all_to_all_single(h_out, h_in, [t.shape[0] for t in outs], [t.shape[0] for t in ins], group=self.group)
+            pos = 0
+            for t in outs:
+                t.copy_(h_out[pos: pos + t.shape[0]])
+                pos += t.shape[0]
+        else:
+            dist.all_to_all(outs, ins, group=self.group)
+
     def send_requests(self, ops, idx_ptr, n, req_ptr, max_index):
         """route + count exchange + id exchange.  ssd_gnn_cache.cuh:111-129 / COALA_GNN_Manager.py:152-165."""
         n = int(n)
-        dev = self.device
-        node = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
-        mp = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+        node = self._buf("node", n, torch.int64)
+        mp = self._buf("map", n, torch.int64)
         ops.route(idx_ptr, n, self.world, node.data_ptr(), mp.data_ptr(), self.counts.data_ptr(), self.offsets.data_ptr(), 0)
         self._a2a(self.recv_counts, self.counts)
         self._both_dev[0].copy_(self.counts)
@@ -114,31 +150,64 @@ class AllToAllExchange(object):
             torch.cuda.current_stream().synchronize()  # the one host synchronisation of the step
         send_c, recv_c = self._both_host[0].tolist(), self._both_host[1].tolist()
         total_recv = int(sum(recv_c))
-        recv_ids = torch.empty(max(total_recv, 1), dtype=torch.int64, device=dev)
+        recv_ids = self._buf("recv_ids", total_recv, torch.int64)
         self._a2a(recv_ids[:total_recv], node[:n], recv_c, send_c)
         self._pending = (n, node, mp, send_c, recv_c, recv_ids, total_recv)
         self.last_send_counts, self.last_recv_counts = send_c, recv_c
 
     def read_feature(self, ops, out_ptr, req_ptr, max_index):
-        """serve + row exchange + un-permute.  ssd_gnn_cache.cuh:132-174 / COALA_GNN_Manager.py:167-209."""
+        """probe + rounds of {fill, row exchange} + un-permute.  ssd_gnn_cache.cuh:132-174 / COALA_GNN_Manager.py:167-209."""
         n, node, mp, send_c, recv_c, recv_ids, total_recv = self._pending
         self._pending = None
-        dev = self.device
-        rows_send = torch.empty((max(total_recv, 1), self.dim), dtype=torch.float32, device=dev)
-        ops.serve(rows_send.data_ptr(), recv_ids.data_ptr(), total_recv)
-        rows_recv = torch.empty((max(n, 1), self.dim), dtype=torch.float32, device=dev)
-        timed = self.profile and rows_recv.is_cuda
-        if timed:
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            ev[0].record()
-        self._a2a(rows_recv[:n], rows_send[:total_recv], send_c, recv_c)
-        if timed:
-            ev[1].record()
-            self._row_events.append(ev)
+        G, me, dim = self.world, self.rank, self.dim
+        sdis = [sum(send_c[:p]) for p in range(G)]
+        rdis = [sum(recv_c[:p]) for p in range(G)]
+        rows_send = self._buf("rows_send", total_recv * dim, torch.float32)[: max(total_recv, 1) * dim].view(-1, dim)
+        rows_recv = self._buf("rows_recv", n * dim, torch.float32)[: max(n, 1) * dim].view(-1, dim)
+        K = 1 if G == 1 else self.rounds
+        if total_recv:
+            # one batch per owner and step: the concatenation in source-rank order; the own segment lands in the caller's tensor
+            ops.serve_probe_redirect(rows_send.data_ptr(), recv_ids.data_ptr(), total_recv, rdis[me], rdis[me] + recv_c[me],
+                                     out_ptr, mp.data_ptr() + sdis[me] * 8)
+        fill = _round_slices(recv_c, rdis, K, me)      # owner side: positions of the batch / rows of rows_send
+        land = _round_slices(send_c, sdis, K, me)      # requester side: rows of rows_recv (bucket order, like `node`)
+        cur = torch.cuda.current_stream() if rows_send.is_cuda else None
+        timed = self.profile and rows_recv.is_cuda and G > 1
+        ev_t = None
+        done = []
+        for k in range(K):
+            if total_recv:
+                rng = [r for r in fill[k] if r[1] > r[0]]
+                if k == K - 1 and recv_c[me]:
+                    rng.append((rdis[me], rdis[me] + recv_c[me]))  # own segment: nobody waits for it on a link
+                ops.serve_fill_ranges(rows_send.data_ptr(), recv_ids.data_ptr(), total_recv, rng)
+            if G == 1:
+                continue
+            if self._side is not None:
+                ev = torch.cuda.Event()
+                ev.record(cur)
+                self._side.wait_event(ev)
+                with torch.cuda.stream(self._side):
+                    if timed and k == 0:
+                        ev_t = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                        ev_t[0].record()
+                    self._a2a_slices(rows_recv, land[k], rows_send, fill[k])
+                    if timed and k == K - 1:
+                        ev_t[1].record()
+                    e2 = torch.cuda.Event()
+                    e2.record()
+                done.append(e2)
+            else:
+                self._a2a_slices(rows_recv, land[k], rows_send, fill[k])
+                done.append(None)
+        if timed and ev_t is not None:
+            self._row_events.append(ev_t)
             self.rows_a2a_calls += 1
-            self.remote_rows_in += n - int(send_c[self.rank])
-        ops.scatter(out_ptr, rows_recv.data_ptr(), mp.data_ptr(), n)
-        self._keep = (rows_recv, mp)  # until the next step: scatter is stream-ordered, torch's allocator is too
+            self.remote_rows_in += n - int(send_c[me])
+        for k in range(K if G > 1 else 0):  # un-permute round by round as the rows arrive
+            if done[k] is not None:
+                cur.wait_event(done[k])
+            ops.scatter_ranges(out_ptr, rows_recv.data_ptr(), mp.data_ptr(), [r for r in land[k] if r[1] > r[0]])
 
     def fetch(self, ops, out_ptr, idx_ptr, n, max_index=0):
         self.send_requests(ops, idx_ptr, n, 0, max_index)
@@ -146,24 +215,50 @@ class AllToAllExchange(object):
 
 
 class NativeExchange(object):
-    """The same exchange as AllToAllExchange, as ONE native call (coala_cache_fetch_distributed: route, ncclAllToAll of the
-    counts, ncclAllToAllv of ids and rows, serve, un-permute inside libcoala_hip.so).  Own RCCL communicator per cache
-    group, bootstrapped by broadcasting the 128-byte ncclUniqueId over a torch.distributed CPU group."""
+    """The same exchange as ONE native call (coala_cache_fetch_distributed: route, counts, ids, probe with the own shard
+    delivered in place, fill rounds overlapped with row rounds on the communicator's own HIP stream, un-permute -- all
+    inside libcoala_hip.so).  Own RCCL communicator per cache group, bootstrapped by broadcasting the 128-byte ncclUniqueId
+    over a torch.distributed CPU group; or, with inproc_group=, a rank of an in-process group (host threads)."""
 
-    def __init__(self, bootstrap_group, src_global_rank, rank, world, device_index):
+    def __init__(self, bootstrap_group, src_global_rank, rank, world, device_index, inproc_group=None, rounds=None):
         import ctypes as C
         from COALA_GNN_Pybind import _capi
         self._capi, self._C = _capi, C
         self._lib = _capi.load()
         self.rank, self.world = rank, world
-        uid = torch.zeros(128, dtype=torch.uint8)
-        if rank == 0:
-            _capi.check(self._lib.coala_comm_unique_id(uid.data_ptr(), 128))
-        if world > 1:
-            dist.broadcast(uid, src=src_global_rank, group=bootstrap_group)
         self._h = C.c_void_p()
-        _capi.check(self._lib.coala_comm_create(uid.data_ptr(), rank, world, int(device_index), C.byref(self._h)))
+        if inproc_group is not None:
+            _capi.check(self._lib.coala_comm_create_inproc(inproc_group, rank, int(device_index), C.byref(self._h)))
+        else:
+            uid = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                _capi.check(self._lib.coala_comm_unique_id(uid.data_ptr(), 128))
+            if world > 1:
+                dist.broadcast(uid, src=src_global_rank, group=bootstrap_group)
+            _capi.check(self._lib.coala_comm_create(uid.data_ptr(), rank, world, int(device_index), C.byref(self._h)))
+        if rounds is not None:
+            _capi.check(self._lib.coala_comm_set_rounds(self._h, int(rounds)))
+        self.rccl_ranks = int(self._lib.coala_comm_size(self._h))
         self.last_send_counts = self.last_recv_counts = None
+        self._profile = False
+
+    # same profiling surface as AllToAllExchange (bench.py's xGMI figure)
+    @property
+    def profile(self):
+        return self._profile
+
+    @profile.setter
+    def profile(self, on):
+        self._profile = bool(on)
+        self._capi.check(self._lib.coala_comm_profile(self._h, 1 if on else 0, None, 0))
+
+    def fold_profile(self):
+        p = self._capi.CommProfile()
+        self._capi.check(self._lib.coala_comm_profile(self._h, -1, self._C.byref(p), 0))
+        return p.rows_ms, int(p.calls), int(p.remote_rows_in)
+
+    def reset_profile(self):
+        self._capi.check(self._lib.coala_comm_profile(self._h, -1, None, 1))
 
     def fetch(self, ops, out_ptr, idx_ptr, n, max_index=0):
         from COALA_GNN_Pybind import current_stream
@@ -174,7 +269,7 @@ class NativeExchange(object):
         self._lib.coala_comm_last_counts(self._h, send, recv)
         self.last_send_counts, self.last_recv_counts = list(send), list(recv)
 
-    # SSD_GNN_NVSHMEM_Cache.send_requests / read_feature keep the reference's two-call sequence: the first call does it all
+    # SSD_GNN_NVSHMEM_Cache.send_requests / read_feature keep the reference's two-call sequence: the second call does it all
     def send_requests(self, ops, idx_ptr, n, req_ptr, max_index):
         self._pending = (idx_ptr, n)
 
@@ -228,12 +323,19 @@ class COALA_GNN_Manager(object):
         dm = None if node_distributor is None else node_distributor.distribute_manager
         G = MPI_comm_manager.local_size
         self.exchange = None
-        # "torch": torch.distributed all_to_all_single on the per-machine RCCL group (default).  "native": the fused C call
-        # with its own RCCL communicator (COALA_EXCHANGE=native).
+        # "native": the fused C call with its own RCCL communicator -- the default whenever the cache group really is an RCCL
+        # group of more than one rank.  "torch": the same sequence driven from Python over torch.distributed (the default for
+        # one rank, and the only choice over a gloo group).  COALA_EXCHANGE overrides.
         import os
-        exchange = exchange or os.environ.get("COALA_EXCHANGE", "torch")
+        if exchange is None:
+            exchange = os.environ.get("COALA_EXCHANGE")
+        if exchange is None:
+            grp = MPI_comm_manager.nccl_cache_gather
+            rccl = G > 1 and grp is not None and dist.is_initialized() and dist.get_backend(grp) == "nccl"
+            exchange = "native" if rccl else "torch"
         if exchange not in ("torch", "native"):
             raise ValueError("exchange must be 'torch' or 'native'")
+        self.exchange_kind = exchange
 
         def make_exchange():
             if exchange == "native":
@@ -242,7 +344,7 @@ class COALA_GNN_Manager(object):
             return AllToAllExchange(MPI_comm_manager.nccl_cache_gather, MPI_comm_manager.local_rank, G, dim, self.device)
         if self.cache_backend == "nvshmem":                   # :83-99
             self.nvshmem_manager = NVSHMEM_Manager(0, MPI_comm_manager.local_rank)
-            self.NVshmem_tensor_manager = NVShmem_Tensor_Manager(self.max_sample_size, dim, G, self.device, ring=max(2, int(out_ring)))
+            self.NVshmem_tensor_manager = NVShmem_Tensor_Manager(self.max_sample_size, dim, G, self.device)
             self.COALA_GNN_Cache = SSD_GNN_NVSHMEM_Cache(self.SSD_Controllers, dm, MPI_comm_manager.global_rank, G, cache_size,
                                                          sim_ptr, num_rows=num_rows, profile=profile, sync=False,
                                                          max_batch=self.max_sample_size, rank=MPI_comm_manager.local_rank,

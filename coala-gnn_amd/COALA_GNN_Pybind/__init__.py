@@ -264,6 +264,29 @@ class _CacheBase:
         """Second phase: cold fill of batch positions [begin, end) (coala_cache_serve_fill)."""
         check(_lib.coala_cache_serve_fill(self._h, int(out_ptr), int(ids_ptr), int(n), int(begin), int(end), current_stream()))
 
+    def serve_probe_redirect(self, out_ptr, ids_ptr, n, begin, end, redirect_out_ptr, row_map_ptr=0):
+        """serve_probe with the batch positions [begin, end) delivered to redirect_out[row_map[pos - begin]] (the requester's own
+        shard of a distributed fetch goes straight into the caller's tensor: coala_cache_serve_probe_redirect)."""
+        rd = _capi.RowRedirect(int(begin), int(end), int(redirect_out_ptr) or None, int(row_map_ptr) or None)
+        check(_lib.coala_cache_serve_probe_redirect(self._h, int(out_ptr) or None, int(ids_ptr) or None, int(n), C.byref(rd), current_stream()))
+
+    def serve_fill_ranges(self, out_ptr, ids_ptr, n, ranges):
+        """Cold fill of a union of disjoint position ranges [(begin, end), ...] of the open batch (coala_cache_serve_fill_ranges)."""
+        k = len(ranges)
+        b = (C.c_int64 * max(k, 1))(*[int(r[0]) for r in ranges])
+        e = (C.c_int64 * max(k, 1))(*[int(r[1]) for r in ranges])
+        check(_lib.coala_cache_serve_fill_ranges(self._h, int(out_ptr) or None, int(ids_ptr) or None, int(n), b, e, k, current_stream()))
+
+    def serve_abort(self):
+        check(_lib.coala_cache_serve_abort(self._h, current_stream()))
+
+    def scatter_ranges(self, out_ptr, src_ptr, map_ptr, ranges):
+        """out[map[r]] = src[r] for the rows r of the ranges [(begin, end), ...] (coala_cache_scatter_ranges)."""
+        k = len(ranges)
+        b = (C.c_int64 * max(k, 1))(*[int(r[0]) for r in ranges])
+        e = (C.c_int64 * max(k, 1))(*[int(r[1]) for r in ranges])
+        check(_lib.coala_cache_scatter_ranges(self._h, int(out_ptr), int(src_ptr), int(map_ptr), b, e, k, current_stream()))
+
     def route(self, idx_ptr, n, n_parts, node_ptr, map_ptr, counts_ptr, offsets_ptr=0, bucket_stride=0):
         check(_lib.coala_cache_route(self._h, int(idx_ptr), int(n), int(n_parts), int(bucket_stride), int(node_ptr),
                                      int(map_ptr), int(counts_ptr), int(offsets_ptr) or None, current_stream()))

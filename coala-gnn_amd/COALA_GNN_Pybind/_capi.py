@@ -29,7 +29,15 @@ class CacheGeometry(C.Structure):
 class CacheProfile(C.Structure):
     _fields_ = [("gather_ms", C.c_double), ("gather_launches", C.c_uint64), ("gather_rows", C.c_uint64),
                 ("gather_hits", C.c_uint64), ("fill_ms", C.c_double), ("fill_launches", C.c_uint64),
-                ("fill_rows", C.c_uint64), ("rank_ms", C.c_double), ("event_overhead_us", C.c_double)]
+                ("fill_rows", C.c_uint64), ("event_overhead_us", C.c_double)]
+
+
+class RowRedirect(C.Structure):
+    _fields_ = [("begin", C.c_int64), ("end", C.c_int64), ("out", C.c_void_p), ("row_map", C.c_void_p)]
+
+
+class CommProfile(C.Structure):
+    _fields_ = [("rows_ms", C.c_double), ("calls", C.c_uint64), ("remote_rows_in", C.c_uint64)]
 
 
 # every exported symbol of include/coala_hip.h: name -> (restype, argtypes)
@@ -46,12 +54,22 @@ SYMBOLS = {
     "coala_cache_serve": (_I, [_VP, _VP, _VP, _I64, _VP]),
     "coala_cache_serve_probe": (_I, [_VP, _VP, _VP, _I64, _VP]),
     "coala_cache_serve_fill": (_I, [_VP, _VP, _VP, _I64, _I64, _I64, _VP]),
+    "coala_cache_serve_fill_ranges": (_I, [_VP, _VP, _VP, _I64, C.POINTER(_I64), C.POINTER(_I64), _I, _VP]),
+    "coala_cache_serve_abort": (_I, [_VP, _VP]),
+    "coala_cache_serve_probe_redirect": (_I, [_VP, _VP, _VP, _I64, C.POINTER(RowRedirect), _VP]),
     "coala_cache_route": (_I, [_VP, _VP, _I64, _I, _I64, _VP, _VP, _VP, _VP, _VP]),
     "coala_cache_scatter": (_I, [_VP, _VP, _VP, _VP, _I64, _VP]),
+    "coala_cache_scatter_ranges": (_I, [_VP, _VP, _VP, _VP, C.POINTER(_I64), C.POINTER(_I64), _I, _VP]),
     "coala_cache_row_dim": (_I64, [_VP]),
     "coala_comm_unique_id": (_I, [_VP, _SZ]),
     "coala_comm_create": (_I, [_VP, _I, _I, _I, C.POINTER(_VP)]),
     "coala_comm_destroy": (_I, [_VP]),
+    "coala_comm_size": (_I, [_VP]),
+    "coala_comm_group_create": (_I, [_I, C.POINTER(_VP)]),
+    "coala_comm_group_destroy": (_I, [_VP]),
+    "coala_comm_create_inproc": (_I, [_VP, _I, _I, C.POINTER(_VP)]),
+    "coala_comm_set_rounds": (_I, [_VP, _I]),
+    "coala_comm_profile": (_I, [_VP, _I, C.POINTER(CommProfile), _I]),
     "coala_comm_last_counts": (_I, [_VP, _VP, _VP]),
     "coala_cache_fetch_distributed": (_I, [_VP, _VP, _VP, _VP, _I64, _VP]),
     "coala_cache_color_counts": (_I, [_VP, _VP, C.c_int32, _VP]),

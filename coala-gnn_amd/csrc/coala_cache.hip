@@ -27,6 +27,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <utility>
 #include <vector>
 
 #include "../../include/coala_hip.h"
@@ -80,6 +81,33 @@ __device__ __forceinline__ uint64_t cold_row_of(const CacheDev& c, uint64_t id) 
     return id / c.n_gpus;
 }
 
+// A union of disjoint batch-position ranges walked as one dense "virtual" index space (a serve split into several fills, a
+// row exchange split into rounds: every round touches one slice of every peer's segment).  Lives in the kernarg segment.
+constexpr int kMaxRanges = 64;
+struct RangeSet {
+    uint32_t n;                      // ranges in use
+    uint32_t total;                  // rows in all ranges
+    uint32_t begin[kMaxRanges];      // first position of range k
+    uint32_t vstart[kMaxRanges + 1]; // exclusive prefix sums of the range lengths
+};
+// position of virtual row v (0xFFFFFFFF past the end).  Uniform trip count: the table is read with scalar loads.
+__device__ __forceinline__ uint32_t pos_of(const RangeSet& rs, uint32_t v) {
+    if (rs.n == 1) return v < rs.total ? rs.begin[0] + v : 0xFFFFFFFFu;
+    uint32_t pos = 0xFFFFFFFFu;
+    for (uint32_t k = 0; k < rs.n; ++k) {
+        const uint32_t a = rs.vstart[k], b = rs.vstart[k + 1];
+        if (v >= a && v < b) pos = rs.begin[k] + (v - a);
+    }
+    return pos;
+}
+// Batch positions [begin, end) are delivered to out[row_map[pos - begin]] of ANOTHER buffer instead of row pos of the batch's
+// own output: the requester's own shard of a distributed fetch goes straight into the caller's tensor, bypassing the exchange.
+struct Redirect {
+    int64_t begin, end;
+    float* out;
+    const int64_t* row_map; // null: row pos - begin
+};
+
 __device__ __forceinline__ uint64_t readlane64(uint64_t v, int src_lane) {
     uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)v, src_lane);
     uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src_lane);
@@ -121,10 +149,12 @@ constexpr int kK1Waves = 2; // waves per block (measured: 2048 x 128 threads bea
 template <typename V> __device__ __forceinline__ V nt_load(const V* p) { return __builtin_nontemporal_load(p); }
 template <typename V> __device__ __forceinline__ void nt_store(V v, V* p) { __builtin_nontemporal_store(v, p); }
 
-template <int CD, int VEC, int NP = 4, bool FULL = false, bool NOMISS = false /* development only: tools/k1_bench */>
+template <int CD, int VEC, int NP = 4, bool FULL = false, bool NOMISS = false /* development only: tools/k1_bench */, bool REDIR = false>
 __global__ __launch_bounds__(64 * kK1Waves, K1_MIN_WAVES) void probe_gather_kernel(CacheDev c, const int64_t* __restrict__ idx,
-                                                                    float* __restrict__ out, int64_t n, uint32_t gen) {
+                                                                    float* __restrict__ out, int64_t n, uint32_t gen, Redirect rd) {
     // FULL: dim == cache_dim, every lane of a row group moves data -> no per-lane bounds predicate around the row moves
+    // REDIR: rows at positions [rd.begin, rd.end) go to rd.out[rd.row_map[..]] (own shard of a distributed fetch); the
+    //        destination row travels with the id through the software pipeline, so no load sits in front of the stores
     using G = Geo<CD, VEC, NP>;
     using V = typename VecT<VEC>::type;
     constexpr int R = G::R;
@@ -136,8 +166,8 @@ __global__ __launch_bounds__(64 * kK1Waves, K1_MIN_WAVES) void probe_gather_kern
     const uint32_t nunits = c.dim / VEC; // accesses per output row
 
     // probe state of one chunk: lane l looks at row q = 4t + l/16, keys 2(l%16), 2(l%16)+1 of that row's set
-    struct Ids { uint64_t id[TSTEPS]; bool valid[TSTEPS]; };
-    struct Tags { uint64_t id[TSTEPS]; uint64_t set[TSTEPS]; vu64x2 kk[TSTEPS]; bool ok[TSTEPS]; bool valid[TSTEPS]; };
+    struct Ids { uint64_t id[TSTEPS]; bool valid[TSTEPS]; int64_t drow[REDIR ? TSTEPS : 1]; };
+    struct Tags { uint64_t id[TSTEPS]; uint64_t set[TSTEPS]; vu64x2 kk[TSTEPS]; bool ok[TSTEPS]; bool valid[TSTEPS]; int64_t drow[REDIR ? TSTEPS : 1]; };
     auto load_ids = [&](int64_t chunk) {
         Ids r;
 #pragma unroll
@@ -146,6 +176,11 @@ __global__ __launch_bounds__(64 * kK1Waves, K1_MIN_WAVES) void probe_gather_kern
             const int64_t i_l = chunk * R + q_l;
             r.valid[t] = (chunk < n_chunks) && (q_l < R) && (i_l < n);
             r.id[t] = r.valid[t] ? (uint64_t)idx[i_l] : 0;
+            if (REDIR) { // destination row: >= 0 row of the batch's own output, < 0 encodes row -(v+1) of rd.out
+                int64_t d = i_l;
+                if (r.valid[t] && i_l >= rd.begin && i_l < rd.end) d = -((rd.row_map ? rd.row_map[i_l - rd.begin] : i_l - rd.begin) + 1);
+                r.drow[t] = d;
+            }
         }
         return r;
     };
@@ -155,6 +190,7 @@ __global__ __launch_bounds__(64 * kK1Waves, K1_MIN_WAVES) void probe_gather_kern
         for (int t = 0; t < TSTEPS; ++t) {
             r.id[t] = ids.id[t];
             r.valid[t] = ids.valid[t];
+            if (REDIR) r.drow[t] = ids.drow[t];
             r.ok[t] = ids.valid[t] && ids.id[t] < c.num_rows;
             r.set[t] = r.ok[t] ? set_of(c, ids.id[t]) : 0;
             r.kk[t] = vu64x2{kEmptyKey, kEmptyKey};
@@ -171,6 +207,7 @@ __global__ __launch_bounds__(64 * kK1Waves, K1_MIN_WAVES) void probe_gather_kern
     for (; chunk < n_chunks; chunk += n_waves) {
         const int64_t base = chunk * R;
         uint32_t slot[R];       // wave-uniform: set*32 + way for hits
+        int64_t drow[REDIR ? R : 1]; // wave-uniform: destination row (REDIR only)
         uint32_t hitmask = 0;   // bit q: row q hits
         uint32_t missmask = 0;  // bit q: row q misses (valid, in range, no tag match)
         uint32_t badmask = 0;   // bit q: id outside [0, num_rows)
@@ -202,6 +239,7 @@ __global__ __launch_bounds__(64 * kK1Waves, K1_MIN_WAVES) void probe_gather_kern
                         badmask |= 1u << q;
                     }
                     slot[q] = (uint32_t)(set_q * COALA_WAYS) + way;
+                    if (REDIR) drow[q] = (int64_t)readlane64((uint64_t)tags.drow[t], 16 * qq);
                     if (lane == q) my_set = set_q;
                 }
             }
@@ -243,6 +281,10 @@ __global__ __launch_bounds__(64 * kK1Waves, K1_MIN_WAVES) void probe_gather_kern
             const bool h = (hitmask >> q) & 1;
             const bool bad = (badmask >> q) & 1;
             V* dst = reinterpret_cast<V*>(out + (base + q) * (int64_t)c.dim);
+            if (REDIR) {
+                const int64_t dr = (G::RPP == 2) ? (sub ? drow[p * G::RPP + (G::RPP - 1)] : drow[p * G::RPP]) : drow[p];
+                if (dr < 0) dst = reinterpret_cast<V*>(rd.out + (-(dr + 1)) * (int64_t)c.dim);
+            }
 #pragma unroll
             for (int v = 0; v < G::VPL; ++v) {
                 const uint32_t u = v * G::LPR + l_in;
@@ -271,22 +313,22 @@ __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src) {
     return ((uint64_t)hi << 32) | lo;
 }
 
-template <int CD, int VEC, int NP = 4>
+template <int CD, int VEC, bool REDIR = false, int NP = 4>
 __global__ __launch_bounds__(256) void miss_fill_kernel(CacheDev c, const int64_t* __restrict__ idx, float* __restrict__ out,
-                                                        int64_t n, int tile_rows, int64_t begin, int64_t end) {
-    // Works on batch positions [begin, end) (the whole batch, or one slice of a serve split into several fills).
-    // A wave reads the verdicts of tile_rows rows at once (one byte per lane; tile_rows = R or 64) and then works through
-    // the tile chunk by chunk (R rows), skipping chunks without a miss on a scalar mask.  With tile_rows = R this is one
-    // verdict load per chunk: fine when the grid is wide (HBM cold tier).  Behind the 16..64-block grid of the host tier it
-    // made a batch with few misses latency-bound (123,904 rows, all hits: 484 dependent loads per wave = 220 us of nothing).
+                                                        int tile_rows, RangeSet rs, Redirect rd) {
+    // Works on the batch positions of `rs` (the whole batch = one range, or the slices of a serve split into several fills),
+    // walked as one dense virtual index space.  A wave reads the verdicts of tile_rows rows at once (one byte per lane;
+    // tile_rows = R or 64) and then works through the tile chunk by chunk (R rows), skipping chunks without a miss on a scalar
+    // mask.  With tile_rows = R this is one verdict load per chunk: fine when the grid is wide (HBM cold tier).  Behind the
+    // 16..64-block grid of the host tier it made a batch with few misses latency-bound (123,904 rows, all hits: 484 dependent
+    // loads per wave = 220 us of nothing).
     using G = Geo<CD, VEC, NP>;
     using V = typename VecT<VEC>::type;
     constexpr int R = G::R;
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
-    const int64_t tile_first = begin / tile_rows;
-    const int64_t n_tiles = (end + tile_rows - 1) / tile_rows; // one past the last tile
+    const int64_t n_tiles = ((int64_t)rs.total + tile_rows - 1) / tile_rows;
     const int chunks_per_tile = tile_rows / R;
     const uint32_t nunits = c.dim / VEC;
     const int sub = (G::RPP == 2) ? (lane >> 5) : 0;
@@ -294,21 +336,23 @@ __global__ __launch_bounds__(256) void miss_fill_kernel(CacheDev c, const int64_
     uint32_t my_miss = 0, my_bad = 0;
 
     constexpr int U = 4; // verdict loads in flight per wave: the scan of a batch without misses is a chain of load latencies
-    for (int64_t tile0 = tile_first + wave; tile0 < n_tiles; tile0 += n_waves * U) {
+    for (int64_t tile0 = wave; tile0 < n_tiles; tile0 += n_waves * U) {
       uint32_t st_pack = 0; // the U verdict bytes of this lane, one per tile
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-          const int64_t p = (tile0 + u * n_waves) * tile_rows + lane;
-          const uint8_t v = (tile0 + u * n_waves < n_tiles && lane < tile_rows && p >= begin && p < end) ? c.row_state[p] : (uint8_t)0;
+          const int64_t tile = tile0 + u * n_waves;
+          const uint32_t p = (tile < n_tiles && lane < tile_rows) ? pos_of(rs, (uint32_t)(tile * tile_rows + lane)) : 0xFFFFFFFFu;
+          const uint8_t v = (p != 0xFFFFFFFFu) ? c.row_state[p] : (uint8_t)0;
           st_pack |= (uint32_t)v << (8 * u);
       }
       if (!__ballot(st_pack != 0)) continue; // nothing but hits in these U tiles
 #pragma nounroll
       for (int u = 0; u < U; ++u) {
-        const int64_t tile_base = (tile0 + u * n_waves) * tile_rows;
-        const int64_t pos_l = tile_base + lane;
         const uint8_t st = (uint8_t)(st_pack >> (8 * u));
         const uint64_t tile_mask = __ballot(st == 1);
+        if (!__ballot(st != 0)) continue;
+        // a lane with a verdict has a valid position (recomputed: cheaper than keeping U of them alive across the loop)
+        const uint32_t pos_l = st ? pos_of(rs, (uint32_t)((tile0 + u * n_waves) * tile_rows + lane)) : 0u;
         if (st) c.row_state[pos_l] = 0; // leave the array clean for the next batch
         my_miss += (st == 1);
         my_bad += (st == 2);
@@ -317,19 +361,21 @@ __global__ __launch_bounds__(256) void miss_fill_kernel(CacheDev c, const int64_
             const uint32_t live_mask = (uint32_t)(tile_mask >> (ck * R)) & ((1u << R) - 1u);
             if (!live_mask) continue;
             const int lane0 = ck * R;              // lanes lane0 .. lane0+R-1 hold this chunk's rows
-            const int64_t base = tile_base + lane0;
             // ---- the chunk's lanes holding a miss: rank it inside its set and pick the way
             uint32_t slot_l = 0, win_l = 0;
             uint64_t id_l = 0;
+            int64_t drow_l = (int64_t)pos_l;       // destination row; < 0 encodes row -(v+1) of rd.out
             if (st == 1 && lane >= lane0 && lane < lane0 + R) {
                 id_l = (uint64_t)idx[pos_l];
+                if (REDIR && (int64_t)pos_l >= rd.begin && (int64_t)pos_l < rd.end)
+                    drow_l = -((rd.row_map ? rd.row_map[(int64_t)pos_l - rd.begin] : (int64_t)pos_l - rd.begin) + 1);
                 const uint64_t set = set_of(c, id_l);
                 uint32_t cur = (uint32_t)c.set_head[set]; // tagged with this generation: this row was pushed on it by K1
                 uint32_t total = 0, rank = 0;
                 while (cur) {
                     const uint32_t p2 = cur - 1;
                     ++total;
-                    rank += (p2 < (uint32_t)pos_l) ? 1u : 0u;
+                    rank += (p2 < pos_l) ? 1u : 0u;
                     cur = c.miss_next[p2];
                 }
                 const uint32_t cnt0 = c.set_cnt[set] - total;                       // value before this batch
@@ -352,6 +398,7 @@ __global__ __launch_bounds__(256) void miss_fill_kernel(CacheDev c, const int64_
             V val[G::PASSES][G::VPL];
             uint32_t slot_[G::PASSES];
             uint64_t id[G::PASSES];
+            int64_t drow[G::PASSES];
             bool live[G::PASSES], winner[G::PASSES];
 #pragma unroll
             for (int p = 0; p < G::PASSES; ++p) {
@@ -360,6 +407,7 @@ __global__ __launch_bounds__(256) void miss_fill_kernel(CacheDev c, const int64_
                 slot_[p] = (uint32_t)__shfl((int)slot_l, lane0 + q);
                 winner[p] = __shfl((int)win_l, lane0 + q) != 0;
                 id[p] = shfl64(id_l, lane0 + q);
+                drow[p] = (int64_t)shfl64((uint64_t)drow_l, lane0 + q);
             }
 #pragma unroll
             for (int p = 0; p < G::PASSES; ++p) {
@@ -372,8 +420,8 @@ __global__ __launch_bounds__(256) void miss_fill_kernel(CacheDev c, const int64_
             }
 #pragma unroll
             for (int p = 0; p < G::PASSES; ++p) {
-                const int q = p * G::RPP + sub;
-                V* dst = reinterpret_cast<V*>(out + (uint64_t)(base + q) * c.dim);
+                V* dst = (REDIR && drow[p] < 0) ? reinterpret_cast<V*>(rd.out + (uint64_t)(-(drow[p] + 1)) * c.dim)
+                                                : reinterpret_cast<V*>(out + (uint64_t)drow[p] * c.dim);
                 V* line = reinterpret_cast<V*>(c.lines + (uint64_t)slot_[p] * CD);
 #pragma unroll
                 for (int v = 0; v < G::VPL; ++v) {
@@ -404,14 +452,15 @@ __global__ __launch_bounds__(256) void miss_fill_kernel(CacheDev c, const int64_
 // out[map[r], :] = src[r, :]   (cache_kernel.cu:113-137)
 template <int CD, int VEC, int NP = 4>
 __global__ __launch_bounds__(256) void scatter_rows_kernel(float* __restrict__ out, const float* __restrict__ src,
-                                                           const int64_t* __restrict__ map, int64_t n, uint32_t dim) {
+                                                           const int64_t* __restrict__ map, RangeSet rs, uint32_t dim) {
+    // rows r of `rs` (one range = the whole buffer; several = the slices one round of a split row exchange delivered)
     using G = Geo<CD, VEC, NP>;
     using V = typename VecT<VEC>::type;
     constexpr int R = G::R;
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
-    const int64_t n_chunks = (n + R - 1) / R;
+    const int64_t n_chunks = ((int64_t)rs.total + R - 1) / R;
     const uint32_t nunits = dim / VEC;
     const int sub = (G::RPP == 2) ? (lane >> 5) : 0;
     const int l_in = lane & (G::LPR - 1);
@@ -421,9 +470,10 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(float* __restrict__ o
         int64_t d[G::PASSES];
 #pragma unroll
         for (int p = 0; p < G::PASSES; ++p) {
-            const int64_t r = base + p * G::RPP + sub;
-            d[p] = (r < n) ? map[r] : -1;
-            const V* s = reinterpret_cast<const V*>(src + r * (int64_t)dim);
+            const int64_t vr = base + p * G::RPP + sub;
+            const uint32_t r = (vr < (int64_t)rs.total) ? pos_of(rs, (uint32_t)vr) : 0xFFFFFFFFu;
+            d[p] = (r != 0xFFFFFFFFu) ? map[r] : -1;
+            const V* s = reinterpret_cast<const V*>(src + (int64_t)r * (int64_t)dim);
 #pragma unroll
             for (int v = 0; v < G::VPL; ++v) {
                 const uint32_t u = v * G::LPR + l_in;
@@ -567,6 +617,9 @@ struct coala_cache {
                                           // Full grid: 53.7 GB/s; 8 blocks: 43.1 GB/s.  COALA_K2_GRID overrides.
     int32_t* color_pin = nullptr;         // pinned staging for coala_cache_color_counts
     int64_t open_batch_rows = -1;         // rows of a batch that was probed (serve_probe) and still waits for its fills
+    std::vector<std::pair<int64_t, int64_t>> open_filled; // position ranges of the open batch already handed to a fill (sorted)
+    int64_t open_filled_rows = 0;
+    Redirect open_redirect{0, 0, nullptr, nullptr};       // the open batch's redirect (set by the probe, reused by its fills)
     int k2_tile_rows = 0;                 // rows per verdict tile of K2: 64 for a host cold tier, 0 = one chunk (COALA_K2_TILE_ROWS)
     int k1_passes = 4;                    // rows(-pairs) in flight per wave in K1 (tunable: COALA_K1_PASSES = 2 | 4)
     int k1_grid_cap = 256 * 8;            // K1 blocks (tunable: COALA_K1_GRID)
@@ -619,7 +672,6 @@ void drain_events(coala_cache* h) {
         float ms = 0.f;
         if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
             if (p.kind == 0) { h->prof.gather_ms += ms; h->prof.gather_launches++; h->prof.gather_rows += p.rows; }
-            else if (p.kind == 1) { h->prof.rank_ms += ms; }
             else { h->prof.fill_ms += ms; h->prof.fill_launches++; }
         }
         h->ev_pool.push_back(p.a);
@@ -662,6 +714,28 @@ template <int CD, int VEC> constexpr int geo_cd(Geo<CD, VEC>) { return CD; }
 template <int CD, int VEC> constexpr int geo_vec(Geo<CD, VEC>) { return VEC; }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// Split `count` host ranges into RangeSets of at most kMaxRanges ranges each and call f(rs) for every one.
+template <typename F>
+int for_each_range_set(const int64_t* begins, const int64_t* ends, int count, F&& f) {
+    RangeSet rs;
+    rs.n = 0;
+    rs.total = 0;
+    rs.vstart[0] = 0;
+    for (int k = 0; k < count; ++k) {
+        if (ends[k] <= begins[k]) continue;
+        rs.begin[rs.n] = (uint32_t)begins[k];
+        rs.total += (uint32_t)(ends[k] - begins[k]);
+        rs.vstart[++rs.n] = rs.total;
+        if (rs.n == kMaxRanges) {
+            if (int rc = f(rs)) return rc;
+            rs.n = 0;
+            rs.total = 0;
+        }
+    }
+    if (rs.n) return f(rs);
+    return COALA_OK;
+}
 
 int grid_for(int64_t chunks, int waves_per_block, int max_blocks) {
     int64_t blocks = (chunks + waves_per_block - 1) / waves_per_block;
@@ -818,16 +892,55 @@ int coala_cache_geometry(const coala_cache_t* h, coala_cache_geometry_t* out) {
 enum { kPhaseProbe = 1, kPhaseFill = 2, kPhaseBoth = 3 };
 
 static int read_feature_impl(coala_cache_t* h, float* out, const int64_t* idx, int64_t n, void* stream, bool force_dist,
-                             int phases = kPhaseBoth, int64_t begin = 0, int64_t end = -1) {
+                             int phases, const int64_t* begins, const int64_t* ends, int n_ranges,
+                             const coala_row_redirect_t* redirect) {
     if (!h) return fail(COALA_EINVAL, "null handle");
     if (n < 0 || n > 0x7FFFFFFFll) return fail(COALA_EINVAL, "n=%lld out of range", (long long)n);
-    if (n == 0) return COALA_OK;
-    if (!out || !idx) return fail(COALA_EINVAL, "null buffer");
-    if (end < 0) end = n;
-    if (begin < 0 || begin > end || end > n) return fail(COALA_EINVAL, "fill range [%lld, %lld) outside the batch of %lld rows", (long long)begin, (long long)end, (long long)n);
-    if (!(phases & kPhaseProbe) && (h->open_batch_rows != n || h->gen == 0))
+    if (phases & kPhaseProbe) {
+        // a batch that was probed and not completely filled still owns row_state and the per-set miss chains: a second
+        // probe on top of it would leave stale verdicts behind (K2 is what clears them)
+        if (h->open_batch_rows >= 0)
+            return fail(COALA_EINVAL, "a batch of %lld rows is still open (%lld filled): finish its serve_fill calls or call coala_cache_serve_abort",
+                        (long long)h->open_batch_rows, (long long)h->open_filled_rows);
+    } else if (h->open_batch_rows != n || h->gen == 0) {
         return fail(COALA_EINVAL, "serve_fill without a matching serve_probe (batch of %lld rows, probe saw %lld)", (long long)n, (long long)h->open_batch_rows);
-    if (begin == end && !(phases & kPhaseProbe)) return COALA_OK;
+    }
+    if (n == 0) return COALA_OK;
+    if (!idx || (!out && !(redirect && redirect->begin == 0 && redirect->end == n))) return fail(COALA_EINVAL, "null buffer");
+    Redirect rd{0, 0, nullptr, nullptr};
+    if (phases & kPhaseProbe) {
+        if (redirect && redirect->end > redirect->begin) {
+            if (redirect->begin < 0 || redirect->end > n || !redirect->out)
+                return fail(COALA_EINVAL, "redirect [%lld, %lld) outside the batch of %lld rows, or null destination", (long long)redirect->begin, (long long)redirect->end, (long long)n);
+            rd = Redirect{redirect->begin, redirect->end, redirect->out, redirect->row_map};
+        }
+    } else {
+        rd = h->open_redirect;
+    }
+    const int64_t whole_b = 0, whole_e = n;
+    if (phases == kPhaseBoth) { begins = &whole_b; ends = &whole_e; n_ranges = 1; }
+    int64_t fill_rows = 0;
+    if (phases & kPhaseFill) {
+        if (n_ranges < 0 || (n_ranges > 0 && (!begins || !ends))) return fail(COALA_EINVAL, "bad fill ranges");
+        // every position is filled exactly once per batch: ranges inside [0, n), disjoint from each other and from earlier fills
+        std::vector<std::pair<int64_t, int64_t>> add;
+        for (int k = 0; k < n_ranges; ++k) {
+            if (begins[k] < 0 || begins[k] > ends[k] || ends[k] > n)
+                return fail(COALA_EINVAL, "fill range [%lld, %lld) outside the batch of %lld rows", (long long)begins[k], (long long)ends[k], (long long)n);
+            if (ends[k] > begins[k]) add.emplace_back(begins[k], ends[k]);
+        }
+        if (phases == kPhaseFill) {
+            std::vector<std::pair<int64_t, int64_t>> all = h->open_filled;
+            all.insert(all.end(), add.begin(), add.end());
+            std::sort(all.begin(), all.end());
+            for (size_t k = 1; k < all.size(); ++k)
+                if (all[k].first < all[k - 1].second)
+                    return fail(COALA_EINVAL, "fill range [%lld, %lld) overlaps positions that were already filled in this batch", (long long)all[k].first, (long long)all[k].second);
+            h->open_filled.swap(all);
+        }
+        for (auto& r : add) fill_rows += r.second - r.first;
+        if (fill_rows == 0 && !(phases & kPhaseProbe)) return COALA_OK;
+    }
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipSetDevice(h->cfg.device));
     int rc = ensure_scratch(h, (uint64_t)n, s);
@@ -837,10 +950,16 @@ static int read_feature_impl(coala_cache_t* h, float* out, const int64_t* idx, i
             HIPCHK(hipMemsetAsync(h->d.set_head, 0, h->d.num_sets * 8, s));
             h->gen = 1;
         }
-        h->open_batch_rows = (phases & kPhaseFill) ? -1 : n; // a probe alone leaves the batch open for its fills
+        if (!(phases & kPhaseFill)) { // a probe alone leaves the batch open for its fills
+            h->open_batch_rows = n;
+            h->open_filled.clear();
+            h->open_filled_rows = 0;
+            h->open_redirect = rd;
+        }
     }
     const uint32_t gen = h->gen;
-    const bool vec4 = (h->d.dim % 4 == 0) && aligned16(out) && aligned16(h->d.cold);
+    const bool redir = rd.end > rd.begin;
+    const bool vec4 = (h->d.dim % 4 == 0) && aligned16(out) && aligned16(h->d.cold) && (!redir || aligned16(rd.out));
     CacheDev d = h->d;
     if (force_dist) d.distributed = 1u;
     rc = dispatch_geo(d.cache_dim, vec4, [&](auto geo) -> int {
@@ -852,50 +971,86 @@ static int read_feature_impl(coala_cache_t* h, float* out, const int64_t* idx, i
         if (phases & kPhaseProbe) {
             ProfScope ps(h, s, 0, (uint64_t)n);
             const bool full = (VEC == 4) && ((int)d.dim == CD);
-            if (h->k1_passes == 2) {
+            const dim3 grid(grid_for(chunks, kK1Waves, h->k1_grid_cap)), block(64 * kK1Waves);
+            if (redir) {
+                hipLaunchKernelGGL((probe_gather_kernel<CD, VEC, 4, false, false, true>), grid, block, 0, s, d, idx, out, n, gen, rd);
+            } else if (h->k1_passes == 2) {
                 using G2 = Geo<CD, VEC, 2>;
                 const int64_t chunks2 = (n + G2::R - 1) / G2::R;
-                hipLaunchKernelGGL((probe_gather_kernel<CD, VEC, 2, false>), dim3(grid_for(chunks2, kK1Waves, h->k1_grid_cap)),
-                                   dim3(64 * kK1Waves), 0, s, d, idx, out, n, gen);
+                hipLaunchKernelGGL((probe_gather_kernel<CD, VEC, 2, false>), dim3(grid_for(chunks2, kK1Waves, h->k1_grid_cap)), block, 0, s,
+                                   d, idx, out, n, gen, rd);
             } else if (full) {
-                hipLaunchKernelGGL((probe_gather_kernel<CD, VEC, 4, true>), dim3(grid_for(chunks, kK1Waves, h->k1_grid_cap)),
-                                   dim3(64 * kK1Waves), 0, s, d, idx, out, n, gen);
+                hipLaunchKernelGGL((probe_gather_kernel<CD, VEC, 4, true>), grid, block, 0, s, d, idx, out, n, gen, rd);
             } else {
-                hipLaunchKernelGGL((probe_gather_kernel<CD, VEC, 4, false>), dim3(grid_for(chunks, kK1Waves, h->k1_grid_cap)),
-                                   dim3(64 * kK1Waves), 0, s, d, idx, out, n, gen);
+                hipLaunchKernelGGL((probe_gather_kernel<CD, VEC, 4, false>), grid, block, 0, s, d, idx, out, n, gen, rd);
             }
         }
-        if ((phases & kPhaseFill) && end > begin) {
-            ProfScope ps(h, s, 2, 0);
+        if ((phases & kPhaseFill) && fill_rows > 0) {
             // verdict tile: 64 rows behind the narrow host-tier grid, one chunk behind the wide HBM-tier grid (see the kernel)
             const int tile_rows = h->k2_tile_rows > 0 ? h->k2_tile_rows : G::R;
-            const int64_t tiles = (end + tile_rows - 1) / tile_rows - begin / tile_rows;
-            hipLaunchKernelGGL((miss_fill_kernel<CD, VEC>), dim3(grid_for(tiles, 4, h->k2_grid_cap)), dim3(256), 0,
-                               s, d, idx, out, n, tile_rows, begin, end);
+            return for_each_range_set(begins, ends, n_ranges, [&](const RangeSet& rs) -> int {
+                ProfScope ps(h, s, 2, 0);
+                const int64_t tiles = ((int64_t)rs.total + tile_rows - 1) / tile_rows;
+                const dim3 grid(grid_for(tiles, 4, h->k2_grid_cap));
+                if (redir) hipLaunchKernelGGL((miss_fill_kernel<CD, VEC, true>), grid, dim3(256), 0, s, d, idx, out, tile_rows, rs, rd);
+                else hipLaunchKernelGGL((miss_fill_kernel<CD, VEC, false>), grid, dim3(256), 0, s, d, idx, out, tile_rows, rs, rd);
+                return COALA_OK;
+            });
         }
-        if (phases & kPhaseProbe) h->rows_total += (uint64_t)n;
         return COALA_OK;
     });
     if (rc) return rc;
+    if (phases & kPhaseProbe) h->rows_total += (uint64_t)n;
+    if (phases == kPhaseFill) {
+        h->open_filled_rows += fill_rows;
+        if (h->open_filled_rows == h->open_batch_rows) { // [0, n) covered once: the batch is complete
+            h->open_batch_rows = -1;
+            h->open_filled.clear();
+            h->open_filled_rows = 0;
+        }
+    }
     HIPCHK(hipGetLastError());
     if (h->cfg.flags & COALA_FLAG_SYNC) HIPCHK(hipStreamSynchronize(s));
     return COALA_OK;
 }
 
 int coala_cache_read_feature(coala_cache_t* h, float* out, const int64_t* idx, int64_t n, void* stream) {
-    return read_feature_impl(h, out, idx, n, stream, false);
+    return read_feature_impl(h, out, idx, n, stream, false, kPhaseBoth, nullptr, nullptr, 0, nullptr);
 }
 
 int coala_cache_serve(coala_cache_t* h, float* out, const int64_t* ids, int64_t n, void* stream) {
-    return read_feature_impl(h, out, ids, n, stream, true);
+    return read_feature_impl(h, out, ids, n, stream, true, kPhaseBoth, nullptr, nullptr, 0, nullptr);
 }
 
 int coala_cache_serve_probe(coala_cache_t* h, float* out, const int64_t* ids, int64_t n, void* stream) {
-    return read_feature_impl(h, out, ids, n, stream, true, kPhaseProbe);
+    return read_feature_impl(h, out, ids, n, stream, true, kPhaseProbe, nullptr, nullptr, 0, nullptr);
+}
+
+int coala_cache_serve_probe_redirect(coala_cache_t* h, float* out, const int64_t* ids, int64_t n, const coala_row_redirect_t* redirect,
+                                     void* stream) {
+    return read_feature_impl(h, out, ids, n, stream, true, kPhaseProbe, nullptr, nullptr, 0, redirect);
 }
 
 int coala_cache_serve_fill(coala_cache_t* h, float* out, const int64_t* ids, int64_t n, int64_t begin, int64_t end, void* stream) {
-    return read_feature_impl(h, out, ids, n, stream, true, kPhaseFill, begin, end);
+    return read_feature_impl(h, out, ids, n, stream, true, kPhaseFill, &begin, &end, 1, nullptr);
+}
+
+int coala_cache_serve_fill_ranges(coala_cache_t* h, float* out, const int64_t* ids, int64_t n, const int64_t* begins, const int64_t* ends,
+                                  int n_ranges, void* stream) {
+    return read_feature_impl(h, out, ids, n, stream, true, kPhaseFill, begins, ends, n_ranges, nullptr);
+}
+
+int coala_cache_serve_abort(coala_cache_t* h, void* stream) {
+    if (!h) return fail(COALA_EINVAL, "null handle");
+    if (h->open_batch_rows < 0) return COALA_OK;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    // the probe already advanced the round-robin cursors of the sets that missed: legal (the cursor only picks the next victim);
+    // what must not survive is the verdict array, which only a fill clears
+    HIPCHK(hipMemsetAsync(h->d.row_state, 0, h->cap, (hipStream_t)stream));
+    h->open_batch_rows = -1;
+    h->open_filled.clear();
+    h->open_filled_rows = 0;
+    return COALA_OK;
 }
 
 int coala_cache_route(coala_cache_t* h, const int64_t* idx, int64_t n, int n_parts, int64_t bucket_stride,
@@ -931,10 +1086,16 @@ int coala_cache_route(coala_cache_t* h, const int64_t* idx, int64_t n, int n_par
     return COALA_OK;
 }
 
-int coala_cache_scatter(coala_cache_t* h, float* out, const float* src, const int64_t* map, int64_t n, void* stream) {
+int coala_cache_scatter_ranges(coala_cache_t* h, float* out, const float* src, const int64_t* map, const int64_t* begins,
+                               const int64_t* ends, int n_ranges, void* stream) {
     if (!h) return fail(COALA_EINVAL, "null handle");
-    if (n < 0) return fail(COALA_EINVAL, "negative n");
-    if (n == 0) return COALA_OK;
+    if (n_ranges < 0 || (n_ranges > 0 && (!begins || !ends))) return fail(COALA_EINVAL, "bad ranges");
+    int64_t rows = 0;
+    for (int k = 0; k < n_ranges; ++k) {
+        if (begins[k] < 0 || ends[k] < begins[k] || ends[k] > 0x7FFFFFFFll) return fail(COALA_EINVAL, "bad range [%lld, %lld)", (long long)begins[k], (long long)ends[k]);
+        rows += ends[k] - begins[k];
+    }
+    if (rows == 0) return COALA_OK;
     if (!out || !src || !map) return fail(COALA_EINVAL, "null buffer");
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipSetDevice(h->cfg.device));
@@ -944,14 +1105,22 @@ int coala_cache_scatter(coala_cache_t* h, float* out, const float* src, const in
         constexpr int CD = geo_cd(geo);
         constexpr int VEC = geo_vec(geo);
         using G = Geo<CD, VEC>;
-        const int64_t chunks = (n + G::R - 1) / G::R;
-        hipLaunchKernelGGL((scatter_rows_kernel<CD, VEC>), dim3(grid_for(chunks, 4, 256 * 16)), dim3(256), 0, s, out, src, map, n, dim);
-        return COALA_OK;
+        return for_each_range_set(begins, ends, n_ranges, [&](const RangeSet& rs) -> int {
+            const int64_t chunks = ((int64_t)rs.total + G::R - 1) / G::R;
+            hipLaunchKernelGGL((scatter_rows_kernel<CD, VEC>), dim3(grid_for(chunks, 4, 256 * 16)), dim3(256), 0, s, out, src, map, rs, dim);
+            return COALA_OK;
+        });
     });
     if (rc) return rc;
     HIPCHK(hipGetLastError());
     if (h->cfg.flags & COALA_FLAG_SYNC) HIPCHK(hipStreamSynchronize(s));
     return COALA_OK;
+}
+
+int coala_cache_scatter(coala_cache_t* h, float* out, const float* src, const int64_t* map, int64_t n, void* stream) {
+    if (n < 0) return fail(COALA_EINVAL, "negative n");
+    const int64_t b = 0;
+    return coala_cache_scatter_ranges(h, out, src, map, &b, &n, 1, stream);
 }
 
 int coala_cache_color_counts(coala_cache_t* h, int32_t* dst, int32_t n_entries, void* stream) {

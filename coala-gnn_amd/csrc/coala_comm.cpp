@@ -1,15 +1,31 @@
-// coala_comm.cpp -- the owner-partitioned fetch as ONE native call: route -> RCCL all-to-all (counts) -> all-to-all-v (ids)
-// -> owner serve -> all-to-all-v (rows) -> un-permute, on one HIP stream, one host read (the 2G counts) per minibatch.
+// coala_comm.cpp -- the owner-partitioned fetch as ONE native call, split-phase and overlapped on two HIP streams:
+//
+//   caller's stream : route -> counts all-to-all -> [the one host read] -> ids all-to-all-v -> probe (hits copied; the
+//                     requester's OWN shard written straight into `out`) -> fill round 0 -> fill round 1 ... -> un-permute 0, 1 ...
+//   comm stream     :                                   wait fill 0 -> rows round 0 -> wait fill 1 -> rows round 1 ...
+//
+// Round k ships the k-th slice of EVERY peer's segment (xGMI is point-to-point: an all-to-all is bound by its busiest link,
+// so every round keeps all links loaded), while the PCIe cold fill of the next slice runs beside it.  Own-shard rows never
+// enter the exchange or a staging buffer.  One host synchronisation per minibatch (the 2G counts).
 //
 // Replaces, fused (paths relative to /root/reference): SSD_GNN_NVSHMEM_Cache::send_requests + read_feature
-// (COALA_GNN_Modules/ssd_gnn_cache.cuh:111-174: N x 2 one-sided 8-byte puts, 3 nvshmem_barrier_all, N warp-level row puts) and
-// the "nccl" orchestration in COALA-GNN-Setup/COALA_GNN/COALA_GNN_Manager.py:143-211 (full-capacity all_to_all of ids,
-// G(G-1) serial send/recv of rows).  RCCL's ncclAllToAllv drives every direct xGMI link of the GPU at once.
+// (COALA_GNN_Modules/ssd_gnn_cache.cuh:111-174: N x 2 one-sided 8-byte puts, 3 nvshmem_barrier_all, N warp-level row puts,
+// peers served one by one on G streams :132-174) and the "nccl" orchestration in
+// COALA-GNN-Setup/COALA_GNN/COALA_GNN_Manager.py:143-211 (full-capacity all_to_all of ids, G(G-1) serial send/recv of rows,
+// the `j == i` local copy :195-199).
+//
+// Two transports behind one interface: RCCL (one process per GPU, grouped ncclSend/ncclRecv drive every direct xGMI link at
+// once) and an in-process one (G ranks = G host threads of one process, device-to-device copies ordered by events) used by
+// single-process drivers and by the parity tests, which run the very same orchestration with G logical ranks on one GPU.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
+#include <condition_variable>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -24,12 +40,170 @@
         if (r_ != ncclSuccess) return fail(COALA_ECOMM, "%s failed: %s (%s:%d)", #expr, ncclGetErrorString(r_), __FILE__, __LINE__); \
     } while (0)
 
-struct coala_comm {
+namespace {
+
+constexpr int kMaxRounds = 8;
+
+struct Transport {
+    int rank = 0, nranks = 1;
+    virtual ~Transport() {}
+    // recv[p] = element [me] of rank p's send (one int64 per peer, self included)
+    virtual int all_to_all_i64(const int64_t* send_dev, int64_t* recv_dev, hipStream_t st) = 0;
+    // counts / displacements in elements of elem_bytes bytes; the self segment moves only when include_self
+    virtual int all_to_all_v(const void* send, const size_t* scnt, const size_t* sdis, void* recv, const size_t* rcnt,
+                             const size_t* rdis, size_t elem_bytes, bool include_self, hipStream_t st) = 0;
+    // make the peers fail instead of hang after a local error between collectives; the transport is unusable afterwards
+    virtual void abort() = 0;
+};
+
+// ------------------------------------------------------------------------------------------------------------ RCCL
+struct RcclTransport : Transport {
     ncclComm_t comm = nullptr;
+    ~RcclTransport() override {
+        if (comm) (void)ncclCommDestroy(comm);
+    }
+    int all_to_all_i64(const int64_t* send_dev, int64_t* recv_dev, hipStream_t st) override {
+        NCCLCHK(ncclAllToAll(send_dev, recv_dev, 1, ncclInt64, comm, st));
+        return COALA_OK;
+    }
+    int all_to_all_v(const void* send, const size_t* scnt, const size_t* sdis, void* recv, const size_t* rcnt, const size_t* rdis,
+                     size_t elem_bytes, bool include_self, hipStream_t st) override {
+        const ncclDataType_t dt = (elem_bytes % 8 == 0) ? ncclInt64 : ncclFloat32;
+        const size_t per = (elem_bytes % 8 == 0) ? elem_bytes / 8 : elem_bytes / 4;
+        if (include_self && scnt[rank])
+            HIPCHK(hipMemcpyAsync((char*)recv + rdis[rank] * elem_bytes, (const char*)send + sdis[rank] * elem_bytes, scnt[rank] * elem_bytes,
+                                  hipMemcpyDeviceToDevice, st));
+        NCCLCHK(ncclGroupStart());
+        for (int p = 0; p < nranks; ++p) {
+            if (p == rank) continue;
+            if (scnt[p]) NCCLCHK(ncclSend((const char*)send + sdis[p] * elem_bytes, scnt[p] * per, dt, p, comm, st));
+            if (rcnt[p]) NCCLCHK(ncclRecv((char*)recv + rdis[p] * elem_bytes, rcnt[p] * per, dt, p, comm, st));
+        }
+        NCCLCHK(ncclGroupEnd());
+        return COALA_OK;
+    }
+    void abort() override {
+        if (comm) (void)ncclCommAbort(comm);
+        comm = nullptr;
+    }
+};
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------------------------ in-process
+struct coala_comm_group {
+    int nranks = 0;
+    std::mutex m;
+    std::condition_variable cv;
+    int arrived = 0;
+    uint64_t phase = 0;
+    bool aborted = false;
+    int attached = 0;
+    int timeout_s = 120; // COALA_INPROC_TIMEOUT_S
+    struct Slot {
+        const void* send = nullptr;
+        const size_t* scnt = nullptr;
+        const size_t* sdis = nullptr;
+        hipEvent_t ready = nullptr, done = nullptr;
+    };
+    std::vector<Slot> slot;
+
+    int barrier() { // -> 0, or -1 when the group was aborted
+        std::unique_lock<std::mutex> lk(m);
+        if (aborted) return -1;
+        const uint64_t my = phase;
+        if (++arrived == nranks) {
+            arrived = 0;
+            ++phase;
+            cv.notify_all();
+            return 0;
+        }
+        // a peer that never arrives (it failed before its collective call, or its thread died) must not hang the others forever
+        if (!cv.wait_for(lk, std::chrono::seconds(timeout_s), [&] { return phase != my || aborted; })) {
+            aborted = true;
+            cv.notify_all();
+        }
+        return aborted ? -1 : 0;
+    }
+    void abort() {
+        std::lock_guard<std::mutex> lk(m);
+        aborted = true;
+        cv.notify_all();
+    }
+};
+
+namespace {
+
+struct InprocTransport : Transport {
+    coala_comm_group* g = nullptr;
+    int exchange(const void* send, const size_t* scnt, const size_t* sdis, void* recv, const size_t* rcnt, const size_t* rdis,
+                 size_t elem_bytes, bool include_self, hipStream_t st) {
+        auto& me = g->slot[rank];
+        me.send = send;
+        me.scnt = scnt;
+        me.sdis = sdis;
+        HIPCHK(hipEventRecord(me.ready, st)); // my send buffer is complete at this point of my stream
+        if (g->barrier()) return fail(COALA_ECOMM, "in-process group aborted (a peer failed or did not arrive in time)");
+        for (int p = 0; p < nranks; ++p) {
+            if (p == rank && !include_self) continue;
+            const auto& peer = g->slot[p];
+            if (peer.scnt[rank] != rcnt[p]) {
+                g->abort();
+                return fail(COALA_ECOMM, "in-process exchange: rank %d sends %zu elements to rank %d, which expects %zu", p, peer.scnt[rank], rank, rcnt[p]);
+            }
+            if (!rcnt[p]) continue;
+            if (p != rank) HIPCHK(hipStreamWaitEvent(st, peer.ready, 0));
+            HIPCHK(hipMemcpyAsync((char*)recv + rdis[p] * elem_bytes, (const char*)peer.send + peer.sdis[rank] * elem_bytes, rcnt[p] * elem_bytes,
+                                  hipMemcpyDeviceToDevice, st));
+        }
+        HIPCHK(hipEventRecord(me.done, st)); // I have pulled what I need from everybody
+        if (g->barrier()) return fail(COALA_ECOMM, "in-process group aborted (a peer failed or did not arrive in time)");
+        for (int p = 0; p < nranks; ++p) // nobody reuses its send buffer before every peer has pulled from it
+            if (p != rank) HIPCHK(hipStreamWaitEvent(st, g->slot[p].done, 0));
+        // no third barrier: a peer that races ahead rewrites its slot only before the NEXT exchange's first barrier, which this
+        // rank has to reach too; send / counts are read above, before the second barrier
+        return COALA_OK;
+    }
+    int all_to_all_i64(const int64_t* send_dev, int64_t* recv_dev, hipStream_t st) override {
+        std::vector<size_t> one((size_t)nranks, 1), dis((size_t)nranks);
+        for (int p = 0; p < nranks; ++p) dis[p] = (size_t)p;
+        return exchange(send_dev, one.data(), dis.data(), recv_dev, one.data(), dis.data(), sizeof(int64_t), true, st);
+    }
+    int all_to_all_v(const void* send, const size_t* scnt, const size_t* sdis, void* recv, const size_t* rcnt, const size_t* rdis,
+                     size_t elem_bytes, bool include_self, hipStream_t st) override {
+        return exchange(send, scnt, sdis, recv, rcnt, rdis, elem_bytes, include_self, st);
+    }
+    void abort() override { g->abort(); }
+};
+
+int grow(void** p, uint64_t* cap, uint64_t need, size_t elem, hipStream_t st) {
+    if (need <= *cap) return COALA_OK;
+    HIPCHK(hipStreamSynchronize(st));
+    if (*p) HIPCHK(hipFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    uint64_t c = 4096;
+    while (c < need) c *= 2;
+    if (c - need > (c >> 2) && need > (1ull << 20)) c = need + (need >> 3); // large buffers: 12 % head room instead of up to 100 %
+    if (hipMalloc(p, c * elem) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(COALA_ENOMEM, "hipMalloc(%llu) failed for the exchange workspace", (unsigned long long)(c * elem));
+    }
+    *cap = c;
+    return COALA_OK;
+}
+
+} // namespace
+
+struct coala_comm {
+    Transport* tr = nullptr;
     int rank = 0, nranks = 1, device = 0;
-    // workspace (device), grown on demand
+    int rounds = 2;                 // row-exchange rounds per fetch (COALA_EXCHANGE_ROUNDS; coala_comm_set_rounds)
+    hipStream_t cs = nullptr;       // the communication stream of this rank
+    hipEvent_t ev_fill[kMaxRounds] = {}, ev_x[kMaxRounds] = {};
+    // workspace (device), grown on demand, persistent across steps
     int64_t *node = nullptr, *map = nullptr;
-    uint64_t batch_cap = 0;
+    uint64_t node_cap = 0, map_cap = 0;
     int64_t* recv_ids = nullptr;
     uint64_t recv_cap = 0;
     float *rows_send = nullptr, *rows_recv = nullptr;
@@ -38,20 +212,57 @@ struct coala_comm {
     int64_t* counts_host = nullptr;                // pinned [2G]
     // last step, for tests / diagnostics
     std::vector<int64_t> last_send, last_recv;
+    // profiling of the row exchange (coala_comm_profile)
+    bool profile = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_live;
+    std::vector<hipEvent_t> prof_pool;
+    coala_comm_profile_t prof{};
+    bool broken = false;
 };
 
 namespace {
-int grow(void** p, uint64_t* cap, uint64_t need, size_t elem, hipStream_t st) {
-    if (need <= *cap) return COALA_OK;
-    HIPCHK(hipStreamSynchronize(st));
-    if (*p) HIPCHK(hipFree(*p));
-    *p = nullptr;
-    uint64_t c = *cap ? *cap : 4096;
-    while (c < need) c *= 2;
-    HIPCHK(hipMalloc(p, c * elem));
-    *cap = c;
+
+int finish_create(coala_comm* c) {
+    c->rank = c->tr->rank;
+    c->nranks = c->tr->nranks;
+    if (const char* e = getenv("COALA_EXCHANGE_ROUNDS")) {
+        const int r = atoi(e);
+        if (r >= 1 && r <= kMaxRounds) c->rounds = r;
+    }
+    if (hipStreamCreateWithFlags(&c->cs, hipStreamNonBlocking) != hipSuccess) return fail(COALA_EHIP, "hipStreamCreate failed");
+    for (int k = 0; k < kMaxRounds; ++k)
+        if (hipEventCreateWithFlags(&c->ev_fill[k], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_x[k], hipEventDisableTiming) != hipSuccess)
+            return fail(COALA_EHIP, "hipEventCreate failed");
+    if (hipMalloc((void**)&c->counts_dev, (3 * (size_t)c->nranks + 1) * sizeof(int64_t)) != hipSuccess ||
+        hipHostMalloc((void**)&c->counts_host, 2 * (size_t)c->nranks * sizeof(int64_t)) != hipSuccess)
+        return fail(COALA_ENOMEM, "communicator workspace allocation failed");
+    c->last_send.assign(c->nranks, 0);
+    c->last_recv.assign(c->nranks, 0);
     return COALA_OK;
 }
+
+void drain_profile(coala_comm* c) {
+    for (auto& p : c->prof_live) {
+        float ms = 0.f;
+        if (hipEventSynchronize(p.second) == hipSuccess && hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) c->prof.rows_ms += ms;
+        c->prof_pool.push_back(p.first);
+        c->prof_pool.push_back(p.second);
+    }
+    c->prof_live.clear();
+}
+
+hipEvent_t take_timing_event(coala_comm* c) {
+    if (!c->prof_pool.empty()) {
+        hipEvent_t e = c->prof_pool.back();
+        c->prof_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
 } // namespace
 
 extern "C" {
@@ -69,24 +280,83 @@ int coala_comm_create(const void* id_bytes, int rank, int nranks, int device, co
     *out = nullptr;
     HIPCHK(hipSetDevice(device));
     coala_comm* c = new (std::nothrow) coala_comm();
-    if (!c) return fail(COALA_ENOMEM, "out of host memory");
-    c->rank = rank;
-    c->nranks = nranks;
+    RcclTransport* t = new (std::nothrow) RcclTransport();
+    if (!c || !t) {
+        delete c;
+        delete t;
+        return fail(COALA_ENOMEM, "out of host memory");
+    }
+    c->tr = t;
     c->device = device;
+    t->rank = rank;
+    t->nranks = nranks;
     ncclUniqueId id;
     memcpy(&id, id_bytes, NCCL_UNIQUE_ID_BYTES);
-    ncclResult_t r = ncclCommInitRank(&c->comm, nranks, id, rank);
+    ncclResult_t r = ncclCommInitRank(&t->comm, nranks, id, rank);
     if (r != ncclSuccess) {
-        delete c;
+        coala_comm_destroy(c);
         return fail(COALA_ECOMM, "ncclCommInitRank failed: %s", ncclGetErrorString(r));
     }
-    if (hipMalloc((void**)&c->counts_dev, (3 * (size_t)nranks + 1) * sizeof(int64_t)) != hipSuccess ||
-        hipHostMalloc((void**)&c->counts_host, 2 * (size_t)nranks * sizeof(int64_t)) != hipSuccess) {
+    if (int rc = finish_create(c)) {
         coala_comm_destroy(c);
-        return fail(COALA_ENOMEM, "communicator workspace allocation failed");
+        return rc;
     }
-    c->last_send.assign(nranks, 0);
-    c->last_recv.assign(nranks, 0);
+    *out = c;
+    return COALA_OK;
+}
+
+int coala_comm_group_create(int nranks, coala_comm_group_t** out) {
+    if (!out || nranks < 1 || nranks > 64) return fail(COALA_EINVAL, "bad group size");
+    coala_comm_group* g = new (std::nothrow) coala_comm_group();
+    if (!g) return fail(COALA_ENOMEM, "out of host memory");
+    g->nranks = nranks;
+    g->slot.resize((size_t)nranks);
+    if (const char* e = getenv("COALA_INPROC_TIMEOUT_S")) {
+        const int t = atoi(e);
+        if (t > 0) g->timeout_s = t;
+    }
+    *out = g;
+    return COALA_OK;
+}
+
+int coala_comm_group_destroy(coala_comm_group_t* g) {
+    if (!g) return COALA_OK;
+    if (g->attached) return fail(COALA_EINVAL, "%d communicators of this group are still alive", g->attached);
+    delete g;
+    return COALA_OK;
+}
+
+int coala_comm_create_inproc(coala_comm_group_t* g, int rank, int device, coala_comm_t** out) {
+    if (!g || !out || rank < 0 || rank >= g->nranks) return fail(COALA_EINVAL, "bad in-process communicator arguments");
+    *out = nullptr;
+    HIPCHK(hipSetDevice(device));
+    coala_comm* c = new (std::nothrow) coala_comm();
+    InprocTransport* t = new (std::nothrow) InprocTransport();
+    if (!c || !t) {
+        delete c;
+        delete t;
+        return fail(COALA_ENOMEM, "out of host memory");
+    }
+    c->tr = t;
+    c->device = device;
+    t->g = g;
+    t->rank = rank;
+    t->nranks = g->nranks;
+    auto& sl = g->slot[rank];
+    if (sl.ready || hipEventCreateWithFlags(&sl.ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess) {
+        delete c;
+        delete t;
+        return fail(COALA_EINVAL, "rank %d of the group is taken, or hipEventCreate failed", rank);
+    }
+    {
+        std::lock_guard<std::mutex> lk(g->m);
+        g->attached++;
+    }
+    if (int rc = finish_create(c)) {
+        coala_comm_destroy(c);
+        return rc;
+    }
     *out = c;
     return COALA_OK;
 }
@@ -95,12 +365,35 @@ int coala_comm_destroy(coala_comm_t* c) {
     if (!c) return COALA_OK;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    if (c->comm) (void)ncclCommDestroy(c->comm);
+    drain_profile(c);
+    for (auto e : c->prof_pool) (void)hipEventDestroy(e);
+    if (auto* t = dynamic_cast<InprocTransport*>(c->tr)) {
+        auto& sl = t->g->slot[t->rank];
+        if (sl.ready) (void)hipEventDestroy(sl.ready);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+        sl.ready = sl.done = nullptr;
+        std::lock_guard<std::mutex> lk(t->g->m);
+        t->g->attached--;
+    }
+    delete c->tr;
+    for (int k = 0; k < kMaxRounds; ++k) {
+        if (c->ev_fill[k]) (void)hipEventDestroy(c->ev_fill[k]);
+        if (c->ev_x[k]) (void)hipEventDestroy(c->ev_x[k]);
+    }
+    if (c->cs) (void)hipStreamDestroy(c->cs);
     void* dev[] = {c->node, c->map, c->recv_ids, c->rows_send, c->rows_recv, c->counts_dev};
     for (void* p : dev)
         if (p) (void)hipFree(p);
     if (c->counts_host) (void)hipHostFree(c->counts_host);
     delete c;
+    return COALA_OK;
+}
+
+int coala_comm_size(const coala_comm_t* c) { return c ? c->nranks : 0; }
+
+int coala_comm_set_rounds(coala_comm_t* c, int rounds) {
+    if (!c || rounds < 1 || rounds > kMaxRounds) return fail(COALA_EINVAL, "rounds must be 1..%d", kMaxRounds);
+    c->rounds = rounds;
     return COALA_OK;
 }
 
@@ -113,34 +406,54 @@ int coala_comm_last_counts(const coala_comm_t* c, int64_t* send, int64_t* recv) 
     return COALA_OK;
 }
 
+int coala_comm_profile(coala_comm_t* c, int enable, coala_comm_profile_t* out, int reset) {
+    if (!c) return fail(COALA_EINVAL, "null communicator");
+    HIPCHK(hipSetDevice(c->device));
+    drain_profile(c);
+    if (out) *out = c->prof;
+    if (reset) c->prof = coala_comm_profile_t{};
+    if (enable >= 0) c->profile = enable != 0;
+    return COALA_OK;
+}
+
 int coala_cache_fetch_distributed(coala_cache_t* h, coala_comm_t* c, float* out, const int64_t* idx, int64_t n, void* stream) {
     if (!h || !c) return fail(COALA_EINVAL, "null handle");
-    if (n < 0 || (n > 0 && (!out || !idx))) return fail(COALA_EINVAL, "bad batch");
+    if (c->broken) return fail(COALA_ECOMM, "this communicator failed in an earlier fetch and was aborted: destroy it");
+    // every check that can fail locally comes BEFORE the first collective: a rank that returns between collectives strands its peers
+    if (n < 0 || n > 0x7FFFFFFFll || (n > 0 && (!out || !idx))) return fail(COALA_EINVAL, "bad batch");
     coala_cache_geometry_t geo;
     int rc = coala_cache_geometry(h, &geo);
     if (rc) return rc;
-    const int G = c->nranks;
+    const int G = c->nranks, me = c->rank;
     const int64_t dim = coala_cache_row_dim(h);
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipSetDevice(c->device));
     const uint64_t nb = (uint64_t)(n > 0 ? n : 1);
-    if (nb > c->batch_cap) {
-        uint64_t cap_node = c->batch_cap, cap_map = c->batch_cap;
-        if ((rc = grow((void**)&c->node, &cap_node, nb, sizeof(int64_t), st))) return rc;
-        if ((rc = grow((void**)&c->map, &cap_map, nb, sizeof(int64_t), st))) return rc;
-        c->batch_cap = cap_node < cap_map ? cap_node : cap_map;
-    }
+    if ((rc = grow((void**)&c->node, &c->node_cap, nb, sizeof(int64_t), st))) return rc;
+    if ((rc = grow((void**)&c->map, &c->map_cap, nb, sizeof(int64_t), st))) return rc;
     if ((rc = grow((void**)&c->rows_recv, &c->rows_recv_cap, nb * (uint64_t)dim, sizeof(float), st))) return rc;
+    // the usual step receives about as many ids as it sends: pre-size the owner-side buffers too, so that the grow after the
+    // counts exchange (the one allocation that sits between collectives) only happens for skewed batches
+    if ((rc = grow((void**)&c->recv_ids, &c->recv_cap, nb + (nb >> 2), sizeof(int64_t), st))) return rc;
+    if ((rc = grow((void**)&c->rows_send, &c->rows_send_cap, (nb + (nb >> 2)) * (uint64_t)dim, sizeof(float), st))) return rc;
     int64_t* send_cnt = c->counts_dev;
     int64_t* recv_cnt = c->counts_dev + G;
     int64_t* offsets = c->counts_dev + 2 * G; // [G+1]
     // 1. bucket by owner (stable), packed layout
     if ((rc = coala_cache_route(h, idx, n, G, 0, c->node, c->map, send_cnt, offsets, st))) return rc;
+
+    // from here on a local failure aborts the transport so that the peers error out instead of waiting for this rank
+    auto broke = [&](int code) {
+        c->broken = true;
+        c->tr->abort();
+        return code;
+    };
     // 2. counts: every rank tells every owner how many ids follow
-    NCCLCHK(ncclAllToAll(send_cnt, recv_cnt, 1, ncclInt64, c->comm, st));
+    if ((rc = c->tr->all_to_all_i64(send_cnt, recv_cnt, st))) return broke(rc);
     // 3. the one host read of the step
-    HIPCHK(hipMemcpyAsync(c->counts_host, c->counts_dev, 2 * (size_t)G * sizeof(int64_t), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    if (hipMemcpyAsync(c->counts_host, c->counts_dev, 2 * (size_t)G * sizeof(int64_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+        return broke(fail(COALA_EHIP, "reading the exchange counts failed: %s", hipGetErrorString(hipGetLastError())));
     std::vector<size_t> scnt(G), sdis(G), rcnt(G), rdis(G);
     size_t total_recv = 0, acc = 0;
     for (int p = 0; p < G; ++p) {
@@ -153,19 +466,85 @@ int coala_cache_fetch_distributed(coala_cache_t* h, coala_comm_t* c, float* out,
         c->last_send[p] = (int64_t)scnt[p];
         c->last_recv[p] = (int64_t)rcnt[p];
     }
-    if ((int64_t)acc != n) return fail(COALA_ECOMM, "route produced %zu ids for a batch of %lld", acc, (long long)n);
+    if ((int64_t)acc != n) return broke(fail(COALA_ECOMM, "route produced %zu ids for a batch of %lld", acc, (long long)n));
+    if (total_recv > 0x7FFFFFFFull) return broke(fail(COALA_ECOMM, "%zu ids routed to one owner in one step", total_recv));
     const uint64_t tr = total_recv ? total_recv : 1;
-    if ((rc = grow((void**)&c->recv_ids, &c->recv_cap, tr, sizeof(int64_t), st))) return rc;
-    if ((rc = grow((void**)&c->rows_send, &c->rows_send_cap, tr * (uint64_t)dim, sizeof(float), st))) return rc;
-    // 4. ids to their owners (exact sizes)
-    NCCLCHK(ncclAllToAllv(c->node, scnt.data(), sdis.data(), c->recv_ids, rcnt.data(), rdis.data(), ncclInt64, c->comm, st));
-    // 5. owner side: one batch = the concatenation in source-rank order
-    if ((rc = coala_cache_serve(h, c->rows_send, c->recv_ids, (int64_t)total_recv, st))) return rc;
-    // 6. rows back to the requesters
-    for (int p = 0; p < G; ++p) { scnt[p] *= (size_t)dim; sdis[p] *= (size_t)dim; rcnt[p] *= (size_t)dim; rdis[p] *= (size_t)dim; }
-    NCCLCHK(ncclAllToAllv(c->rows_send, rcnt.data(), rdis.data(), c->rows_recv, scnt.data(), sdis.data(), ncclFloat, c->comm, st));
-    // 7. un-permute into the caller's order
-    if ((rc = coala_cache_scatter(h, out, c->rows_recv, c->map, n, st))) return rc;
+    if ((rc = grow((void**)&c->recv_ids, &c->recv_cap, tr, sizeof(int64_t), st))) return broke(rc);
+    if ((rc = grow((void**)&c->rows_send, &c->rows_send_cap, tr * (uint64_t)dim, sizeof(float), st))) return broke(rc);
+    // 4. ids to their owners (exact sizes); the own bucket is a device copy
+    if ((rc = c->tr->all_to_all_v(c->node, scnt.data(), sdis.data(), c->recv_ids, rcnt.data(), rdis.data(), sizeof(int64_t), true, st)))
+        return broke(rc);
+    // 5. owner side: ONE batch = the concatenation in source-rank order (DESIGN.md "Determinism contract").  Probe all of it;
+    //    the own segment is delivered straight to out[map[..]] -- it never sees rows_send, the exchange or rows_recv.
+    coala_row_redirect_t rd;
+    rd.begin = (int64_t)rdis[me];
+    rd.end = (int64_t)(rdis[me] + rcnt[me]);
+    rd.out = out;
+    rd.row_map = c->map + sdis[me];
+    if ((rc = coala_cache_serve_probe_redirect(h, c->rows_send, c->recv_ids, (int64_t)total_recv, &rd, st))) return broke(rc);
+    // 6. rounds: fill slice k of every peer's segment on the caller's stream, ship it on the comm stream while slice k+1 fills
+    const int K = (G == 1) ? 1 : c->rounds;
+    const size_t row_bytes = (size_t)dim * sizeof(float);
+    std::vector<int64_t> fb(G), fe(G);
+    std::vector<size_t> xs_cnt(G), xs_dis(G), xr_cnt(G), xr_dis(G);
+    std::vector<int64_t> sb((size_t)G * K), se((size_t)G * K); // requester-side ranges of rows_recv, per round
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    if (c->profile && G > 1) {
+        if (c->prof_live.size() >= 4096) drain_profile(c);
+        t0 = take_timing_event(c);
+        t1 = take_timing_event(c);
+    }
+    for (int k = 0; k < K && total_recv > 0; ++k) {
+        int nr = 0;
+        for (int p = 0; p < G; ++p) {
+            int64_t b, e;
+            if (p == me) { // own segment: nobody waits for it on a link -> last round
+                if (k != K - 1) continue;
+                b = (int64_t)rdis[p];
+                e = (int64_t)(rdis[p] + rcnt[p]);
+            } else {
+                b = (int64_t)(rdis[p] + rcnt[p] * (size_t)k / (size_t)K);
+                e = (int64_t)(rdis[p] + rcnt[p] * (size_t)(k + 1) / (size_t)K);
+            }
+            if (e > b) { fb[nr] = b; fe[nr] = e; ++nr; }
+        }
+        if ((rc = coala_cache_serve_fill_ranges(h, c->rows_send, c->recv_ids, (int64_t)total_recv, fb.data(), fe.data(), nr, st))) return broke(rc);
+        if (G > 1 && hipEventRecord(c->ev_fill[k], st) != hipSuccess) return broke(fail(COALA_EHIP, "hipEventRecord failed"));
+    }
+    if (total_recv == 0 && G > 1) // nothing to serve: the rounds below still run (peers may owe this rank rows)
+        for (int k = 0; k < K; ++k)
+            if (hipEventRecord(c->ev_fill[k], st) != hipSuccess) return broke(fail(COALA_EHIP, "hipEventRecord failed"));
+    if (G > 1) {
+        for (int k = 0; k < K; ++k) {
+            for (int p = 0; p < G; ++p) {
+                const size_t a = rcnt[p] * (size_t)k / (size_t)K, b = rcnt[p] * (size_t)(k + 1) / (size_t)K;     // what I serve to p
+                const size_t u = scnt[p] * (size_t)k / (size_t)K, v = scnt[p] * (size_t)(k + 1) / (size_t)K;     // what p serves to me
+                xs_cnt[p] = (p == me) ? 0 : b - a;
+                xs_dis[p] = rdis[p] + a;
+                xr_cnt[p] = (p == me) ? 0 : v - u;
+                xr_dis[p] = sdis[p] + u;
+                sb[(size_t)k * G + p] = (int64_t)(sdis[p] + u);
+                se[(size_t)k * G + p] = (p == me) ? (int64_t)(sdis[p] + u) : (int64_t)(sdis[p] + v);
+            }
+            if (hipStreamWaitEvent(c->cs, c->ev_fill[k], 0) != hipSuccess) return broke(fail(COALA_EHIP, "hipStreamWaitEvent failed"));
+            if (k == 0 && t0) (void)hipEventRecord(t0, c->cs);
+            if ((rc = c->tr->all_to_all_v(c->rows_send, xs_cnt.data(), xs_dis.data(), c->rows_recv, xr_cnt.data(), xr_dis.data(), row_bytes, false, c->cs)))
+                return broke(rc);
+            if (hipEventRecord(c->ev_x[k], c->cs) != hipSuccess) return broke(fail(COALA_EHIP, "hipEventRecord failed"));
+        }
+        if (t0 && t1) {
+            (void)hipEventRecord(t1, c->cs);
+            c->prof_live.emplace_back(t0, t1);
+            c->prof.calls++;
+            c->prof.remote_rows_in += (uint64_t)(n - (int64_t)scnt[me]);
+        }
+        // 7. un-permute round by round as the rows arrive
+        for (int k = 0; k < K; ++k) {
+            if (hipStreamWaitEvent(st, c->ev_x[k], 0) != hipSuccess) return broke(fail(COALA_EHIP, "hipStreamWaitEvent failed"));
+            if ((rc = coala_cache_scatter_ranges(h, out, c->rows_recv, c->map, sb.data() + (size_t)k * G, se.data() + (size_t)k * G, G, st)))
+                return broke(rc);
+        }
+    }
     return COALA_OK;
 }
 

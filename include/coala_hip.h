@@ -105,10 +105,31 @@ int coala_cache_serve(coala_cache_t* h, float* out, const int64_t* ids, int64_t 
 /* The same serve in two phases, for callers that overlap the cold fill with the exchange of rows that are already in place
  * (ssd_gnn_cache.cuh:132-174 serves and ships peer by peer on separate streams): serve_probe classifies the WHOLE batch and
  * copies the hits; serve_fill completes the positions [begin, end) -- ranking still spans the whole batch, so any set of
- * fills that covers [0, n) once, in any order, leaves table, counters and rows exactly as one coala_cache_serve does.
- * Same out / ids / n in every call of one batch; the next probe starts the next batch. */
+ * fills that covers [0, n) exactly once, in any order, leaves table, counters and rows exactly as one coala_cache_serve does.
+ * Same out / ids / n in every call of one batch.  The batch stays OPEN until its fills have covered [0, n): until then any
+ * new probe (read_feature, serve, serve_probe*) and any fill that overlaps an earlier one returns COALA_EINVAL;
+ * coala_cache_serve_abort drops an open batch (its misses stay uncached, rows of unfilled positions are undefined). */
 int coala_cache_serve_probe(coala_cache_t* h, float* out, const int64_t* ids, int64_t n, void* stream);
 int coala_cache_serve_fill(coala_cache_t* h, float* out, const int64_t* ids, int64_t n, int64_t begin, int64_t end, void* stream);
+/* One fill over a union of disjoint position ranges (HOST arrays begins/ends of n_ranges entries): one kernel launch per 64
+ * ranges.  A row exchange split into rounds fills "the k-th slice of every peer's segment" with one call per round. */
+int coala_cache_serve_fill_ranges(coala_cache_t* h, float* out, const int64_t* ids, int64_t n, const int64_t* begins,
+                                  const int64_t* ends, int n_ranges, void* stream);
+int coala_cache_serve_abort(coala_cache_t* h, void* stream);
+
+/* serve_probe with part of the batch delivered elsewhere: rows at batch positions [begin, end) are written to
+ * redirect->out[row_map[pos - begin], 0:dim] (row_map: device int64[end-begin], NULL = row pos - begin) instead of
+ * out[pos, 0:dim], by the probe and by every later fill of the batch.  This is how the requester's OWN shard of a
+ * distributed fetch goes straight into the caller's tensor (the reference's `j == i` local copy,
+ * COALA-GNN-Setup/COALA_GNN/COALA_GNN_Manager.py:195-199) while staying part of the owner's one batch per step.
+ * `out` may be NULL when the redirect covers the whole batch. */
+typedef struct coala_row_redirect {
+    int64_t begin, end;
+    float* out;
+    const int64_t* row_map;
+} coala_row_redirect_t;
+int coala_cache_serve_probe_redirect(coala_cache_t* h, float* out, const int64_t* ids, int64_t n, const coala_row_redirect_t* redirect,
+                                     void* stream);
 
 /* Bucket idx by owner = id % n_parts, stable inside each bucket.  Replaces Isolated_Cache::split_node_list
  * (ssd_gnn_cache.cuh:283-295) / nccl_split_node_list_kernel (cache_kernel.cu:79-91) and the routing half of
@@ -123,6 +144,9 @@ int coala_cache_route(coala_cache_t* h, const int64_t* idx, int64_t n, int n_par
 /* out[map[r], 0:dim] = src[r, 0:dim] for r in [0, n).  Replaces Isolated_Cache::map_feat_data
  * (ssd_gnn_cache.cuh:327-356) / nccl_gather_feature_kernel + block_memcpy (cache_kernel.cu:113-137). */
 int coala_cache_scatter(coala_cache_t* h, float* out, const float* src, const int64_t* map, int64_t n, void* stream);
+/* The same for the rows r of a union of disjoint ranges (HOST arrays): what one round of a split row exchange delivered. */
+int coala_cache_scatter_ranges(coala_cache_t* h, float* out, const float* src, const int64_t* map, const int64_t* begins,
+                               const int64_t* ends, int n_ranges, void* stream);
 
 /* Floats per row of the cold table / output (cfg.dim). */
 int64_t coala_cache_row_dim(const coala_cache_t* h);
@@ -131,19 +155,46 @@ int64_t coala_cache_row_dim(const coala_cache_t* h);
  * Native fused fetch of the owner-partitioned cache over RCCL (one process per GPU, one communicator per cache group).
  * Replaces, in one call: SSD_GNN_NVSHMEM_Cache::send_requests + read_feature (ssd_gnn_cache.cuh:111-174) and the "nccl"
  * orchestration of COALA_GNN_Manager.fetch_feature (COALA-GNN-Setup/COALA_GNN/COALA_GNN_Manager.py:143-211):
- * route -> ncclAllToAll(counts) -> one host read -> ncclAllToAllv(ids) -> serve -> ncclAllToAllv(rows) -> un-permute.
+ * route -> all-to-all(counts) -> one host read -> all-to-all-v(ids) -> probe (own shard straight into `out`) ->
+ * { cold fill of slice k  ||  all-to-all-v(rows of slice k-1) on a second stream } -> un-permute.
  * ------------------------------------------------------------------------------------------------------------ */
 typedef struct coala_comm coala_comm_t;
 /* ncclGetUniqueId: called by ONE rank; the 128 bytes are handed to the others by any side channel (torch.distributed). */
 int coala_comm_unique_id(void* out_id, size_t cap);
-/* ncclCommInitRank: collective over the nranks processes of the group. */
+/* ncclCommInitRank: collective over the nranks processes of the group (one process per GPU, RCCL over xGMI). */
 int coala_comm_create(const void* id_bytes, int rank, int nranks, int device, coala_comm_t** out);
 int coala_comm_destroy(coala_comm_t* c);
+int coala_comm_size(const coala_comm_t* c);
+/* In-process transport: the nranks ranks of a group are host THREADS of one process (one communicator each, any mix of
+ * devices with peer access, several ranks per device allowed); ids and rows move with device-to-device copies ordered by
+ * events.  Same orchestration as over RCCL -- it is how the parity tests run G logical ranks on one GPU, and how a
+ * single-process multi-GPU driver would use the partitioned cache.  The group outlives its communicators. */
+typedef struct coala_comm_group coala_comm_group_t;
+int coala_comm_group_create(int nranks, coala_comm_group_t** out);
+int coala_comm_group_destroy(coala_comm_group_t* g);
+int coala_comm_create_inproc(coala_comm_group_t* g, int rank, int device, coala_comm_t** out);
+/* Row-exchange rounds per fetch, 1..8 (default 2, or COALA_EXCHANGE_ROUNDS): round k ships the k-th slice of every peer's
+ * segment while the cold fill of slice k+1 runs.  Must be the same on every rank. */
+int coala_comm_set_rounds(coala_comm_t* c, int rounds);
 /* per-peer id counts of the last fetch (host int64[nranks] each, either may be NULL) */
 int coala_comm_last_counts(const coala_comm_t* c, int64_t* send, int64_t* recv);
 /* out[i, 0:dim] = row of idx[i], wherever its owner (idx[i] % nranks) is.  Collective: every rank of the communicator calls
- * it once per step (n may be 0).  Synchronises `stream` once, in the middle (the counts); work after that is enqueued. */
+ * it once per step (n may be 0).  Split-phase: ids go out, the owner probes its ONE batch per step (the concatenation of what
+ * it received, in source-rank order), the requester's own shard lands directly in `out`, and the rows of the other peers come
+ * back in rounds on the communicator's own stream while the owner's cold fill of the next round runs on `stream`.
+ * Synchronises `stream` once, in the middle (the counts); everything after that is enqueued, and `stream` is ordered behind
+ * the communicator's stream on return.  Error behaviour: argument and allocation checks happen before the first collective; a
+ * failure after it aborts the transport (ncclCommAbort) so that the peers fail too instead of waiting -- the communicator
+ * then only accepts coala_comm_destroy. */
 int coala_cache_fetch_distributed(coala_cache_t* h, coala_comm_t* c, float* out, const int64_t* idx, int64_t n, void* stream);
+/* Timing of the row exchange (all rounds of a fetch, HIP events on the communicator's stream; includes any wait for the fill of
+ * a later round): enable = 1 / 0 switches it, -1 leaves it; out (nullable) receives the totals since the last reset. */
+typedef struct coala_comm_profile {
+    double rows_ms;          /* summed duration of the row exchange */
+    uint64_t calls;          /* fetches timed */
+    uint64_t remote_rows_in; /* rows received from other ranks */
+} coala_comm_profile_t;
+int coala_comm_profile(coala_comm_t* c, int enable, coala_comm_profile_t* out, int reset);
 
 /* Copy the colour occupancy counters to HOST memory dst[0 .. n_entries).  Replaces get_cache_data
  * (ssd_gnn_cache.cuh:176-186,270-280).  The reference copies num_colors entries; pass num_colors+1 to also get the
@@ -168,7 +219,6 @@ typedef struct coala_cache_profile {
     double fill_ms;
     uint64_t fill_launches;
     uint64_t fill_rows;
-    double rank_ms;          /* unused since the rank step was fused into the fill kernel (always 0) */
     double event_overhead_us; /* median elapsed time of an EMPTY hipEvent bracket on the same stream: what every bracketed */
                               /* launch above includes on top of the kernel itself                                        */
 } coala_cache_profile_t;

@@ -31,6 +31,7 @@ class OracleOps:
 
     def __init__(self, cache, dim):
         self.cache, self.dim = cache, dim
+        self._open = None
 
     def route(self, idx_ptr, n, n_parts, node_ptr, map_ptr, counts_ptr, offsets_ptr=0, bucket_stride=0):
         idx = _arr(idx_ptr, n, np.int64)
@@ -47,6 +48,36 @@ class OracleOps:
     def serve(self, out_ptr, ids_ptr, n):
         if n:
             _arr(out_ptr, n * self.dim, np.float32).reshape(n, self.dim)[:] = self.cache.read_feature(_arr(ids_ptr, n, np.int64), O.SCHED_HITS_FIRST)
+
+    # split-phase serve: the double computes the whole batch at the probe (one oracle batch, like the kernels' K1 over the whole
+    # batch) but DELIVERS a row only when its position is filled -- an exchange that ships a slice before its fill fails here
+    def serve_probe_redirect(self, out_ptr, ids_ptr, n, begin, end, redirect_out_ptr, row_map_ptr=0):
+        assert getattr(self, "_open", None) is None, "probe while a batch is open"
+        rows = self.cache.read_feature(_arr(ids_ptr, n, np.int64), O.SCHED_HITS_FIRST)
+        self._open = dict(rows=rows, n=n, out=out_ptr, begin=begin, end=end, rout=redirect_out_ptr, rmap=row_map_ptr, filled=np.zeros(n, bool))
+
+    def serve_fill_ranges(self, out_ptr, ids_ptr, n, ranges):
+        o = self._open
+        assert o is not None and o["n"] == n and o["out"] == out_ptr
+        out = _arr(out_ptr, n * self.dim, np.float32).reshape(n, self.dim)
+        for b, e in ranges:
+            assert 0 <= b <= e <= n and not o["filled"][b:e].any(), "fill ranges overlap"
+            o["filled"][b:e] = True
+            for pos in range(b, e):
+                if o["begin"] <= pos < o["end"]:
+                    k = pos - o["begin"]
+                    row = int(_arr(o["rmap"] + 8 * k, 1, np.int64)[0]) if o["rmap"] else k
+                    _arr(o["rout"] + row * self.dim * 4, self.dim, np.float32)[:] = o["rows"][pos]
+                else:
+                    out[pos] = o["rows"][pos]
+        if o["filled"].all():
+            self._open = None
+
+    def scatter_ranges(self, out_ptr, src_ptr, map_ptr, ranges):
+        for b, e in ranges:
+            for r in range(b, e):
+                dst = int(_arr(map_ptr + 8 * r, 1, np.int64)[0])
+                _arr(out_ptr + dst * self.dim * 4, self.dim, np.float32)[:] = _arr(src_ptr + r * self.dim * 4, self.dim, np.float32)
 
     def scatter(self, out_ptr, src_ptr, map_ptr, n):
         if n:
@@ -73,7 +104,9 @@ def mode_exchange():
         lists = [rng.choice(rows, size=int(rng.integers(0, 1500)) if step != 2 or g else 0, replace=False).astype(np.int64) for g in range(G)]
         idx = torch.from_numpy(lists[r].copy())
         out = torch.full((max(len(idx), 1), dim), -1.0)
+        ex.rounds = 1 + step % 3                      # the same on every rank
         ex.fetch(ops, out.data_ptr(), idx.data_ptr(), len(idx))
+        assert ops._open is None, "the exchange left a batch open"
         want = O.dist_fetch(ref, lists)
         assert np.array_equal(out.numpy()[: len(idx)], feat[lists[r]]), f"rank {r} step {step}: rows differ"
         assert np.array_equal(want[r], feat[lists[r]])

@@ -84,6 +84,224 @@ def test_partitioned_cache_matches_oracle(hiplib, oracle, G, dim, cache_mb, cold
     table.close()
 
 
+def _loopback_step_split(torch, caches, idx_list, dim, rounds):
+    """The split-phase sequence of coala_comm.cpp / AllToAllExchange with G logical ranks in one process: route, concatenate per
+    owner, probe with the owner's OWN segment redirected into the requester's tensor, then per round {fill slice k of every
+    peer's segment, hand slice k over}, un-permute per round.  A row leaves the owner only in the round that filled it."""
+    G = len(caches)
+    routed = []
+    for r in range(G):
+        idx = idx_list[r]
+        n = idx.numel()
+        node = torch.empty(max(n, 1), dtype=torch.int64, device="cuda")
+        mp = torch.empty(max(n, 1), dtype=torch.int64, device="cuda")
+        cnt = torch.zeros(G, dtype=torch.int64, device="cuda")
+        off = torch.zeros(G + 1, dtype=torch.int64, device="cuda")
+        caches[r].route(idx.data_ptr(), n, G, node.data_ptr(), mp.data_ptr(), cnt.data_ptr(), off.data_ptr(), 0)
+        routed.append((node, mp, cnt.cpu().tolist(), off.cpu().tolist()))
+    outs = [torch.full((max(idx_list[r].numel(), 1), dim), -3.0, dtype=torch.float32, device="cuda") for r in range(G)]
+    rows_recv = [torch.full((max(idx_list[r].numel(), 1), dim), -5.0, dtype=torch.float32, device="cuda") for r in range(G)]
+    owners = []
+    for o in range(G):
+        rc = [routed[s][2][o] for s in range(G)]
+        rd = [sum(rc[:s]) for s in range(G)]
+        ids = torch.cat([routed[s][0][routed[s][3][o]: routed[s][3][o] + rc[s]] for s in range(G)])
+        tot = ids.numel()
+        rows = torch.full((max(tot, 1), dim), -7.0, dtype=torch.float32, device="cuda")
+        if tot:
+            caches[o].serve_probe_redirect(rows.data_ptr(), ids.data_ptr(), tot, rd[o], rd[o] + rc[o], outs[o].data_ptr(),
+                                           routed[o][1].data_ptr() + routed[o][3][o] * 8)
+        owners.append((rc, rd, ids, tot, rows))
+    for k in range(rounds):
+        for o in range(G):
+            rc, rd, ids, tot, rows = owners[o]
+            rng = [(rd[s] + rc[s] * k // rounds, rd[s] + rc[s] * (k + 1) // rounds) for s in range(G) if s != o]
+            if k == rounds - 1:
+                rng.append((rd[o], rd[o] + rc[o]))
+            if tot:
+                caches[o].serve_fill_ranges(rows.data_ptr(), ids.data_ptr(), tot, rng)
+        for r in range(G):                                    # "exchange" of round k + un-permute of what arrived
+            sc, sd = routed[r][2], routed[r][3]
+            land = []
+            for o in range(G):
+                if o == r:
+                    continue
+                rc, rd, _, _, rows = owners[o]
+                a, b = rc[r] * k // rounds, rc[r] * (k + 1) // rounds
+                assert sc[o] == rc[r]
+                rows_recv[r][sd[o] + a: sd[o] + b] = rows[rd[r] + a: rd[r] + b]
+                land.append((sd[o] + a, sd[o] + b))
+            caches[r].scatter_ranges(outs[r].data_ptr(), rows_recv[r].data_ptr(), routed[r][1].data_ptr(), land)
+    return [outs[r][: idx_list[r].numel()] for r in range(G)]
+
+
+def _dist_fixture(P, oracle, G, dim, cache_mb, cold_part, num_rows, seed, cls="SSD_GNN_NVSHMEM_Cache"):
+    feat = oracle.make_features(num_rows, dim, seed=seed)
+    ctrl = P.SSD_GNN_SSD_Controllers(1, 4096, 1024, 0, 0, dim, True)
+    if cold_part:
+        tables = [PinnedTable(P, np.ascontiguousarray(feat[r::G])) for r in range(G)]
+    else:
+        tables = [PinnedTable(P, feat)] * G
+    caches = [getattr(P, cls)(ctrl, None, r, G, cache_mb, tables[r].device_ptr, num_rows=num_rows, rank=r, cold_partitioned=cold_part)
+              for r in range(G)]
+    orcs = [oracle.OracleCache(cache_mb, dim, feat, n_gpus=G, distributed=True) for _ in range(G)]
+    return feat, tables, caches, orcs
+
+
+@pytest.mark.parametrize("G,dim,cache_mb,cold_part,rounds", [(2, 1024, 1, False, 2), (4, 128, 1, False, 3), (3, 100, 1, True, 2),
+                                                             (8, 1024, 2, True, 2), (4, 256, 1, True, 1), (2, 512, 1, False, 4)])
+def test_split_phase_partitioned_cache_matches_oracle(hiplib, oracle, G, dim, cache_mb, cold_part, rounds):
+    """Own-shard bypass + fills in rounds + un-permute in rounds == the one-serve path == orc_dist_fetch, bit for bit
+    (rows, hit/miss counters, tag table, round-robin cursors)."""
+    import torch
+    num_rows = 12000
+    feat, tables, caches, orcs = _dist_fixture(hiplib, oracle, G, dim, cache_mb, cold_part, num_rows, seed=4)
+    rng = np.random.default_rng(G + 10 * rounds)
+    for step in range(6):
+        sizes = [int(rng.integers(0, 3000)) if step else 1500 for _ in range(G)]
+        if step == 3:
+            sizes[0] = 0  # a rank with an empty batch
+        if step == 4:
+            sizes = [s if r == 1 else 0 for r, s in enumerate(sizes)]  # one requester only: owners serve, most receive nothing
+        idx_np = [rng.choice(num_rows // 2, size=s, replace=step == 5).astype(np.int64) for s in sizes]  # last step: duplicates
+        idx_t = [torch.from_numpy(i).cuda() if len(i) else torch.zeros(0, dtype=torch.int64, device="cuda") for i in idx_np]
+        outs = _loopback_step_split(torch, caches, idx_t, dim, rounds)
+        want = oracle.dist_fetch(orcs, idx_np, oracle.SCHED_HITS_FIRST)
+        for r in range(G):
+            assert outs[r].cpu().numpy().tobytes() == feat[idx_np[r]].tobytes() == want[r].tobytes(), f"rank {r} step {step}"
+            assert caches[r].stats()[:2] == (orcs[r].hit_cnt, orcs[r].miss_cnt), f"owner {r} counters differ at step {step}"
+            keys, cnt, _ = caches[r].dump()
+            assert np.array_equal(keys, orcs[r].keys()) and np.array_equal(cnt, orcs[r].set_cnt())
+    assert sum(o.hit_cnt for o in orcs) > 0
+    for c in caches:
+        c.close()
+    for t in set(tables):
+        t.close()
+
+
+@pytest.mark.parametrize("G,dim,cache_mb,cold_part,rounds", [(2, 1024, 1, False, 2), (3, 100, 1, True, 2), (4, 256, 1, True, 3),
+                                                             (8, 1024, 2, True, 2), (4, 128, 1, False, 1)])
+def test_native_fetch_inproc_ranks_match_oracle(hiplib, oracle, G, dim, cache_mb, cold_part, rounds):
+    """coala_cache_fetch_distributed itself -- the fused native call the product uses at N > 1 -- with G ranks as G host
+    threads of this process on one GPU (in-process transport instead of RCCL, same orchestration: two streams, rounds,
+    own-shard bypass), against orc_dist_fetch: rows, owner counters, tag tables, cursors, per-peer counts."""
+    import ctypes as C
+    import threading
+    import torch
+    from COALA_GNN.COALA_GNN_Manager import NativeExchange
+    from COALA_GNN_Pybind import _capi
+    L = _capi.load()
+    num_rows, steps = 12000, 6
+    feat, tables, caches, orcs = _dist_fixture(hiplib, oracle, G, dim, cache_mb, cold_part, num_rows, seed=6, cls="Isolated_Cache")
+    group = C.c_void_p()
+    _capi.check(L.coala_comm_group_create(G, C.byref(group)))
+    exs = [NativeExchange(None, 0, r, G, 0, inproc_group=group, rounds=rounds) for r in range(G)]
+    rng = np.random.default_rng(77 + G)
+    plan = []
+    for step in range(steps):
+        sizes = [int(rng.integers(0, 3000)) if step else 1500 for _ in range(G)]
+        if step == 2:
+            sizes[G - 1] = 0
+        if step == 4:
+            sizes = [s if r == 0 else 0 for r, s in enumerate(sizes)]
+        plan.append([rng.choice(num_rows // 2, size=s, replace=step == 5).astype(np.int64) for s in sizes])
+    got = [[None] * G for _ in range(steps)]
+    stats = [[None] * G for _ in range(steps)]
+    counts = [[None] * G for _ in range(steps)]
+    errors = []
+    bar = threading.Barrier(G, timeout=180)
+
+    def worker(r):
+        try:
+            torch.cuda.set_device(0)
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                for step in range(steps):
+                    ids = plan[step][r]
+                    idx = torch.from_numpy(ids).cuda() if len(ids) else torch.zeros(0, dtype=torch.int64, device="cuda")
+                    out = torch.full((max(len(ids), 1), dim), -9.0, dtype=torch.float32, device="cuda")
+                    exs[r].fetch(caches[r], out.data_ptr() if len(ids) else 0, idx.data_ptr() if len(ids) else 0, len(ids))
+                    stream.synchronize()
+                    got[step][r] = out[: len(ids)].cpu().numpy()
+                    counts[step][r] = (list(exs[r].last_send_counts), list(exs[r].last_recv_counts))
+                    bar.wait()                      # every owner has finished serving this step
+                    stats[step][r] = caches[r].stats()
+                    bar.wait()
+        except BaseException as e:  # noqa: BLE001
+            errors.append((r, repr(e)))
+            bar.abort()
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(G)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    for step in range(steps):
+        want = oracle.dist_fetch(orcs, plan[step], oracle.SCHED_HITS_FIRST)
+        for r in range(G):
+            assert got[step][r].tobytes() == feat[plan[step][r]].tobytes() == want[r].tobytes(), f"rank {r} step {step}: rows differ"
+            assert stats[step][r][:2] == (orcs[r].hit_cnt, orcs[r].miss_cnt), f"owner {r} counters differ at step {step}"
+            send, recv = counts[step][r]
+            assert send == [int((plan[step][r] % G == o).sum()) for o in range(G)]
+            assert recv == [int((plan[step][s] % G == r).sum()) for s in range(G)]
+    for r in range(G):
+        keys, cnt, _ = caches[r].dump()
+        assert np.array_equal(keys, orcs[r].keys()) and np.array_equal(cnt, orcs[r].set_cnt())
+    assert sum(o.hit_cnt for o in orcs) > 0
+    for e in exs:
+        e.close()
+    _capi.check(L.coala_comm_group_destroy(group))
+    for c in caches:
+        c.close()
+    for t in set(tables):
+        t.close()
+
+
+def test_open_batch_is_guarded(hiplib, oracle):
+    """a probe while a probed batch still waits for fills, a fill that overlaps an earlier one, or a fill for another
+    batch size must be refused (stale verdicts would corrupt the next batch); serve_abort drops the open batch."""
+    import torch
+    P = hiplib
+    dim, num_rows, n = 128, 4000, 600
+    feat = oracle.make_features(num_rows, dim, seed=3)
+    table = PinnedTable(P, feat)
+    ctrl = P.SSD_GNN_SSD_Controllers(1, 512, 1024, 0, 0, dim, True)
+    c = P.SSD_GNN_NVSHMEM_Cache(ctrl, None, 0, 1, 1, table.device_ptr, num_rows=num_rows, rank=0)
+    orc = oracle.OracleCache(1, dim, feat, n_gpus=1, distributed=True)
+    ids = np.random.default_rng(0).choice(num_rows, size=n, replace=False).astype(np.int64)
+    d_ids = torch.from_numpy(ids).cuda()
+    out = torch.full((n, dim), -1.0, device="cuda")
+    c.serve_probe(out.data_ptr(), d_ids.data_ptr(), n)
+    for bad in (lambda: c.serve_probe(out.data_ptr(), d_ids.data_ptr(), n), lambda: c.serve(out.data_ptr(), d_ids.data_ptr(), n),
+                lambda: c._read(out.data_ptr(), d_ids.data_ptr(), n)):
+        with pytest.raises(RuntimeError, match="still open"):
+            bad()
+    c.serve_fill(out.data_ptr(), d_ids.data_ptr(), n, 0, 200)
+    with pytest.raises(RuntimeError, match="overlaps"):
+        c.serve_fill(out.data_ptr(), d_ids.data_ptr(), n, 100, 300)
+    with pytest.raises(RuntimeError, match="overlaps"):
+        c.serve_fill_ranges(out.data_ptr(), d_ids.data_ptr(), n, [(300, 400), (350, 360)])
+    with pytest.raises(RuntimeError, match="outside"):
+        c.serve_fill(out.data_ptr(), d_ids.data_ptr(), n, 500, n + 1)
+    c.serve_fill_ranges(out.data_ptr(), d_ids.data_ptr(), n, [(400, n), (200, 400)])   # coverage complete: the batch closes
+    orc.read_feature(ids, oracle.SCHED_HITS_FIRST, want_rows=False)
+    torch.cuda.synchronize()
+    assert out.cpu().numpy().tobytes() == feat[ids].tobytes()
+    with pytest.raises(RuntimeError, match="without a matching"):
+        c.serve_fill(out.data_ptr(), d_ids.data_ptr(), n, 0, 1)
+    # abort: the next batch starts clean (no stale verdicts), the aborted batch's misses stay uncached
+    ids2 = np.random.default_rng(1).choice(num_rows, size=n, replace=False).astype(np.int64)
+    d2 = torch.from_numpy(ids2).cuda()
+    c.serve_probe(out.data_ptr(), d2.data_ptr(), n)
+    c.serve_abort()
+    c.serve(out.data_ptr(), d_ids.data_ptr(), n)               # the first batch again: every row a hit, nothing stale
+    torch.cuda.synchronize()
+    assert out.cpu().numpy().tobytes() == feat[ids].tobytes()
+    c.close()
+    table.close()
+
+
 @pytest.mark.parametrize("backend,exchange", [("isolated", None), ("nccl", "torch"), ("nvshmem", "torch"), ("nccl", "native"),
                                               ("nvshmem", "native")])
 def test_manager_world1_gpu(hiplib, oracle, backend, exchange):

@@ -198,7 +198,12 @@ class AllToAllExchange(object):
                     e2.record()
                 done.append(e2)
             else:
+                if timed and k == 0:
+                    ev_t = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    ev_t[0].record()
                 self._a2a_slices(rows_recv, land[k], rows_send, fill[k])
+                if timed and k == K - 1:
+                    ev_t[1].record()
                 done.append(None)
         if timed and ev_t is not None:
             self._row_events.append(ev_t)

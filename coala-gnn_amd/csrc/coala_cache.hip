@@ -651,7 +651,9 @@ int ensure_scratch(coala_cache* h, uint64_t n, hipStream_t s) {
     if (h->d.row_state) HIPCHK(hipFree(h->d.row_state));
     h->d.row_state = nullptr;
     HIPCHK(hipMalloc((void**)&h->d.row_state, cap));
-    HIPCHK(hipMemset(h->d.row_state, 0, cap)); // K1 marks non-hits, K2 clears them again
+    // K1 marks non-hits, K2 clears them again.  On the CALLER's stream: a null-stream memset is not ordered against a
+    // non-blocking stream and could land after K1's marks (seen as unfilled rows on the first batch of a handle).
+    HIPCHK(hipMemsetAsync(h->d.row_state, 0, cap, s));
     h->cap = cap;
     return COALA_OK;
 }

@@ -55,13 +55,17 @@ def parse_args():
     ap.add_argument("--epoch-steps", type=int, default=-1,
                     help="end-to-end leg (loader + GraphSAGE step): -1 = one FULL epoch per mode (measured, not extrapolated), "
                          "k > 0 = k steps extrapolated to an epoch, 0 = skip")
-    ap.add_argument("--epoch-prefetch-multi", action="store_true",
-                    help="N>1: also run the epoch leg with the prefetching loader (the exchange's RCCL communicator and DDP's are then "
-                         "driven from two host threads; not validated on multi-GPU hardware yet, hence opt-in)")
-    ap.add_argument("--epoch-timeout", type=float, default=180.0,
-                    help="N>1: seconds after which the epoch leg is abandoned and the JSON line printed without it")
+    ap.add_argument("--epoch-prefetch-multi", dest="epoch_prefetch_multi", action="store_true", default=True,
+                    help="N>1: after the serial epoch leg has succeeded, also run it with the prefetching loader (default)")
+    ap.add_argument("--no-epoch-prefetch-multi", dest="epoch_prefetch_multi", action="store_false",
+                    help="N>1: serial loader only (with prefetch the exchange's RCCL communicator and DDP's are driven from two host threads)")
+    ap.add_argument("--epoch-timeout", type=float, default=240.0,
+                    help="N>1: seconds after which the extra legs are abandoned: the JSON line is printed with an error field and every "
+                         "rank exits with code 3")
     ap.add_argument("--exchange", type=str, default=None, choices=["torch", "native"],
-                    help="N>1: torch.distributed all_to_all_single (default) or the fused native RCCL call")
+                    help="N>1: the fused native RCCL call (default whenever the cache group is an RCCL group) or the same sequence "
+                         "driven from Python over torch.distributed")
+    ap.add_argument("--no-fanout-leg", action="store_true", help="skip the extra fan-out 10,10 leg (BASELINE.json configs[2] batch shape)")
     ap.add_argument("--cold-tier", type=str, default="host", choices=["host", "hbm"],
                     help="host: pinned host memory, zero-copy over PCIe (the workload BASELINE.json names). hbm: the whole table "
                          "resident in this GPU's 288 GB HBM (not the headline configuration; MI355X placement data point)")
@@ -72,6 +76,68 @@ def parse_args():
 def log(msg):
     if int(os.environ.get("RANK", "0")) == 0:
         print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
+class RankGuard(object):
+    """N>1: keeps a hang or a rank-local failure VISIBLE.  A rank that fails raises a flag in the torch.distributed store and
+    exits non-zero; a monitor thread on every rank polls the flag and a deadline, and when either fires rank 0 prints the JSON
+    line (with an "error" field and whatever is finished) and every rank leaves with a non-zero code -- ranks blocked inside a
+    collective included.  Nothing is restarted or re-executed: the process just ends, and torch.distributed.run reports failure."""
+    KEY = "coala_bench_failed"
+
+    def __init__(self, rank, world):
+        import threading
+        self.rank, self.world = rank, world
+        self.line = None          # rank 0: the JSON line as far as it is known
+        self.partial = None       # dict of the leg in progress (shown under "epoch" on failure)
+        self.deadline, self.what = None, ""
+        self.store = dist.distributed_c10d._get_default_store() if world > 1 and dist.is_initialized() else None
+        self._stop = threading.Event()
+        self._t = None
+        if self.store is not None:
+            self._t = threading.Thread(target=self._watch, daemon=True)
+            self._t.start()
+
+    def arm(self, seconds, what):
+        self.what = what
+        self.deadline = time.time() + seconds
+
+    def disarm(self):
+        self.deadline = None
+
+    def close(self):
+        self._stop.set()
+
+    def _leave(self, msg, code):
+        if self.rank == 0:
+            line = dict(self.line) if self.line is not None else {"metric": "feature-gather GB/s", "value": None, "n_gpus": self.world}
+            line["error"] = msg
+            if self.partial is not None:
+                line["epoch"] = dict(self.partial, error=msg)
+            print(json.dumps(line), flush=True)
+        print(f"[bench] rank {self.rank}: leaving with code {code}: {msg}", file=sys.stderr, flush=True)
+        os._exit(code)
+
+    def _watch(self):
+        while not self._stop.wait(0.5):
+            try:
+                if self.store.check([self.KEY]):
+                    self._leave("a rank failed: " + self.store.get(self.KEY).decode(errors="replace"), 4)
+            except Exception:  # noqa: BLE001 -- the store went away with rank 0: nothing left to wait for
+                self._leave("the rendezvous store is gone (rank 0 left)", 4)
+            if self.deadline is not None and time.time() > self.deadline:
+                self._leave(f"{self.what} abandoned by the watchdog (no completion within its time limit)", 3)
+
+    def fail(self, exc):
+        """Called by the rank that caught an exception: tell the others, then leave non-zero."""
+        msg = f"rank {self.rank}: {exc!r}"
+        if self.store is not None:
+            try:
+                self.store.set(self.KEY, msg)
+            except Exception:  # noqa: BLE001
+                pass
+            time.sleep(2.0)       # let rank 0's monitor print the line first (it exits the job's rendezvous store with it)
+        self._leave(msg, 4)
 
 
 def main():
@@ -112,6 +178,26 @@ def main():
     comm = MPI_Comm_Manager(0, backend="gloo" if single_dev else None)   # one machine: every rank in domain 0
     comm.device_index = dev_index
     comm.initialize_nested_process_group(backend)
+    guard = RankGuard(rank, world)
+    guard.arm(1500.0, "setup + timed region")
+    try:
+        _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, device, backend, comm, guard)
+    except SystemExit:
+        raise
+    except BaseException as e:  # noqa: BLE001
+        if world == 1:
+            raise
+        import traceback
+        traceback.print_exc()
+        guard.fail(e)
+    finally:
+        guard.close()
+
+
+def _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, device, backend, comm, guard):
+    from COALA_GNN.COALA_GNN_Manager import COALA_GNN_Manager
+    from COALA_GNN.synthetic import PinnedFeatureTable, feature_rows_torch, fill_table, fill_table_partition, powerlaw_csc
+    from COALA_GNN.sampler import NeighborSampler
 
     # ---------------------------------------------------------------- cold tier: fp32 [rows, dim] in pinned host memory
     t0 = time.time()
@@ -212,6 +298,16 @@ def main():
     for s in range(args.warmup):
         manager.fetch_feature((batches[s],))
     torch.cuda.synchronize()
+    # parity self-check on every rank, untimed: the rows this path just delivered == the synthetic table's formula, bit for bit.
+    # (At N>1 this is the first time the exchange runs over real RCCL links: a wrong row must stop the run, not be timed.)
+    chk_ids = batches[0]
+    got = manager.fetch_feature((chk_ids,))[-1]
+    want = feature_rows_torch(chk_ids, args.dim, args.seed)
+    if not torch.equal(got, want):
+        bad = int((got != want).any(dim=1).sum())
+        raise RuntimeError(f"parity self-check failed on rank {rank}: {bad} of {chk_ids.numel()} delivered rows differ from the table")
+    del got, want
+    torch.cuda.synchronize()
     cache.stats(reset=True)
     cache.profile(reset=True)
     xch = manager.exchange if world > 1 and hasattr(manager.exchange, "reset_profile") else None
@@ -286,7 +382,7 @@ def main():
     achieved = (alg_bytes / launches) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     roofline = {
         "bound": "hbm", "kernel": "probe_gather_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": _pmc_traffic(args, world),
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": _pmc_traffic(args, world)[0], "traffic_source": _pmc_traffic(args, world)[1],
         "frac_of_measured_copy_6290": round(achieved / HBM_COPY_GBS, 4),
         "avg_launch_us": round(k_ms * 1e3, 2), "event_bracket_overhead_us": round(prof.event_overhead_us, 2),
         "launches": int(prof.gather_launches),
@@ -351,7 +447,11 @@ def main():
                                    f"mode={args.mode}",
                        "rows_per_step_per_gpu": round(rows_all / world / args.steps, 1),
                        "hit_ratio": round(hit_all / max(hit_all + miss_all, 1.0), 4),
-                       "cache_backend": backend, **({"TEST_HOOK_single_device": True} if single_dev else {}), "cold_tier": "HBM" if args.cold_tier == "hbm" else ("pinned host, owner-partitioned" if cold_partitioned else "pinned host"),
+                       "cache_backend": backend, **({"TEST_HOOK_single_device": True} if single_dev else {}),
+                       "exchange_transport": getattr(manager, "exchange_kind", None) if world > 1 else None,
+                       "rccl_ranks": (getattr(manager.exchange, "rccl_ranks", None) or
+                                      (dist.get_world_size(comm.nccl_cache_gather) if not single_dev else None)) if world > 1 else None,
+                       "parity_check": "rows of one warm-up minibatch == synthetic table formula, bit-exact, on every rank", "cold_tier": "HBM" if args.cold_tier == "hbm" else ("pinned host, owner-partitioned" if cold_partitioned else "pinned host"),
                        "prewarm_steps": args.prewarm, "rows_scale_factor": rows_scale,
                        "steps_per_epoch": steps_per_epoch,
                        "epoch_time_s_fetch_only_extrapolated": round(ms_per_step * steps_per_epoch / 1e3, 2)},
@@ -365,56 +465,38 @@ def main():
     else:
         line = None
 
-    # ---------------------------------------------------------------- extra leg: end-to-end training steps (epoch time)
-    # Runs last.  At N>1 it is new ground for every collective path at once (exchange + DDP), so a watchdog guarantees the
-    # JSON line: if the leg does not finish in --epoch-timeout seconds every rank gives up and rank 0 prints what it has.
+    # ---------------------------------------------------------------- extra legs: epoch (end to end) and fan-out 10,10
+    # They run last and never cost the headline number silently: at N>1 a rank-local exception or a stall ends the whole job
+    # with a non-zero exit code, after rank 0 has printed the line with an "error" field (RankGuard).
+    guard.line = line
     if args.mode == "minibatch" and args.epoch_steps != 0:
         partial = {}
-        watchdog = None
-        if world > 1:
-            import threading
-
-            def give_up():
-                if rank == 0:
-                    partial["error"] = f"extra legs abandoned by the watchdog after {args.epoch_timeout:.0f} s"
-                    line["epoch"] = partial
-                    print(json.dumps(line), flush=True)
-                os._exit(0)
-            watchdog = threading.Timer(args.epoch_timeout, give_up)
-            watchdog.daemon = True
-            watchdog.start()
-        try:
-            epoch = run_epoch_leg(args, comm, graph, sampler, table, device, fanout, steps_per_epoch, backend=backend,
-                                  cold_partitioned=cold_partitioned, world=world, dev_index=dev_index, single_dev=single_dev,
-                                  out=partial)
-        except Exception as e:  # noqa: BLE001 -- the headline number must still be reported
-            if world == 1:
-                raise
-            log(f"epoch leg failed: {e!r}")
-            partial["error"] = repr(e)
-            epoch = partial
+        guard.partial = partial
+        guard.arm(args.epoch_timeout, "epoch leg")
+        epoch = run_epoch_leg(args, comm, graph, sampler, table, device, fanout, steps_per_epoch, backend=backend,
+                              cold_partitioned=cold_partitioned, world=world, dev_index=dev_index, single_dev=single_dev,
+                              out=partial, guard=guard)
+        guard.partial = None
         if rank == 0:
             line["epoch"] = epoch
-        # ---------------------------------------------------------------- extra leg (N>1): BASELINE.json configs[2]
-        # the configuration named for the 8-GPU run (fan-out 10,10): a short fetch-only measurement next to the weak-scaling
-        # value above (which keeps the N=1 fan-out so that the driver's per-N values are comparable)
-        if world > 1 and args.fanout == "5,5" and "error" not in (epoch or {}):
-            try:
-                extra = run_fanout_leg(args, comm, graph, table, device, [10, 10], backend, cold_partitioned, world, rank,
-                                       train_ids, steps_per_epoch, single_dev)
-            except Exception as e:  # noqa: BLE001
-                log(f"fan-out 10,10 leg failed: {e!r}")
-                extra = {"error": repr(e)}
-            if rank == 0:
-                line["config_fanout_10_10"] = extra
-        if watchdog is not None:
-            watchdog.cancel()
+    # BASELINE.json configs[2] names fan-out 10,10 for the 8-GPU run: a short fetch-only measurement of that batch shape on the
+    # same table / graph / cache size, at EVERY N (so that its per-N curve has an origin at N = 1), next to the weak-scaling
+    # `value` above, which keeps the N = 1 fan-out so that the driver's per-N values stay comparable
+    if args.mode == "minibatch" and args.fanout == "5,5" and not args.no_fanout_leg:
+        guard.arm(args.epoch_timeout, "fan-out 10,10 leg")
+        extra = run_fanout_leg(args, comm, graph, table, device, [10, 10], backend, cold_partitioned, world, rank, train_ids,
+                               steps_per_epoch, single_dev)
+        if rank == 0:
+            line["config_fanout_10_10"] = extra
+    guard.disarm()
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
+        guard.arm(120.0, "teardown")
         dist.barrier()
     del manager
     if world > 1:
+        guard.close()
         comm.destroy_process_group()
 
 
@@ -438,22 +520,25 @@ def run_fanout_leg(args, comm, graph, table, device, fanout, backend, cold_parti
     batches = [ids_for(prewarm + s_) for s_ in range(steps)]
     torch.cuda.synchronize()
     mgr.COALA_GNN_Cache.stats(reset=True)
-    dist.barrier()
+    if world > 1:
+        dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     rows = 0
     for b in batches:
         rows += mgr.fetch_feature((b,))[-1].shape[0]
     torch.cuda.synchronize()
-    dist.barrier()
+    if world > 1:
+        dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     hit, miss, _ = mgr.COALA_GNN_Cache.stats()
     t = torch.tensor([dt, float(rows), float(hit), float(miss)], dtype=torch.float64, device="cpu" if single_dev else device)
-    tmax = t.clone()
-    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    dt = float(tmax[0])
+    if world > 1:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dt = float(tmax[0])
     del mgr
     return {"workload": f"same table and cache, GraphSAGE fan-out {','.join(map(str, fanout))} bs={args.batch} (BASELINE.json configs[2])",
             "value": round(float(t[1]) * args.dim * 4 / dt / 1e9, 3), "unit": "GB/s", "steps": steps, "prewarm_steps": prewarm,
@@ -462,7 +547,7 @@ def run_fanout_leg(args, comm, graph, table, device, fanout, backend, cold_parti
 
 
 def run_epoch_leg(args, comm, graph, sampler, table, device, fanout, steps_per_epoch, backend="isolated", cold_partitioned=False,
-                  world=1, dev_index=0, single_dev=False, out=None):
+                  world=1, dev_index=0, single_dev=False, out=None, guard=None):
     """distribute -> sample -> fetch -> GraphSAGE fwd/bwd/Adam per step, through COALA_GNN_DataLoader: serial (the reference's
     __next__) and with the prefetching producer.  N>1: the same loop on every rank (global batch = batch x N, the partitioned
     cache behind the RCCL exchange, DistributedDataParallel model as in examples/sbatch_ssd_gnn_train.py:112); the time of a
@@ -476,11 +561,14 @@ def run_epoch_leg(args, comm, graph, sampler, table, device, fanout, steps_per_e
                          + (", DistributedDataParallel" if world > 1 else ""),
                 "per_step": "distribute + sample + fetch_feature + forward/backward/optimizer", "steps_per_epoch": steps_per_epoch,
                 "cache_backend": backend})
+    # serial first: at N>1 the prefetching loader (exchange and DDP collectives issued from two host threads) only runs behind
+    # a serial leg that completed on every rank
     modes = [("serial", 0), ("prefetch", 2)]
     if world > 1 and not args.epoch_prefetch_multi:
         modes = modes[:1]
         out["prefetch"] = None
-        out["note"] = "N>1 runs the serial loader only; --epoch-prefetch-multi adds the prefetching one"
+        out["note"] = "--no-epoch-prefetch-multi: serial loader only"
+    inject = os.environ.get("COALA_BENCH_INJECT_FAIL", "")  # test hook "rank:leg": that rank raises at the start of that leg
 
     def across_ranks(secs, nodes):
         if world == 1:
@@ -505,6 +593,10 @@ def run_epoch_leg(args, comm, graph, sampler, table, device, fanout, steps_per_e
         train_ids = torch.randperm(n_train, generator=torch.Generator().manual_seed(1))[: min(n_train, need)]
         graph.ndata["labels"] = (torch.arange(args.rows, device=device) * 7) % 19
         for name, prefetch in modes:
+            if guard is not None:
+                guard.arm(args.epoch_timeout, f"epoch leg ({name})")
+            if inject == f"{comm.global_rank}:{name}":
+                raise RuntimeError(f"injected failure on rank {comm.global_rank} in the {name} epoch leg (COALA_BENCH_INJECT_FAIL)")
             nd = Node_Distributor(comm, train_ids, args.batch, *files, parsing_method="baseline")
             loader = COALA_GNN_DataLoader(SSD_INFO(1, args.dim * 4, 1024, 0), nd, graph, sampler, args.batch, args.dim, fanout,
                                           args.cache_mb, device, cache_backend=backend, sim_buf=table, num_rows=args.rows,
@@ -542,18 +634,20 @@ def run_epoch_leg(args, comm, graph, sampler, table, device, fanout, steps_per_e
 
 
 def _pmc_traffic(args, world):
-    """HBM bytes per launch of the probe+gather kernel from the committed rocprofv3 PMC pass of THIS workload
-    (tools/profile_round.sh -> profiles/pmc_probe_gather.json: separate --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 as
-    MI355X_MICROARCH.md prescribes for gfx950), or None when the command line is not the profiled default."""
+    """(HBM bytes per launch of the probe+gather kernel, where the figure comes from): the committed rocprofv3 PMC pass of THIS
+    workload (tools/profile_round.sh -> profiles/pmc_probe_gather.json: separate --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE
+    x2 as MI355X_MICROARCH.md prescribes for gfx950) -- a constant read from a tracked file, not a live measurement of this run;
+    (None, None) when the command line is not the profiled default."""
     default = (args.rows, args.dim, args.fanout, args.batch, args.cache_mb, args.mode, world, args.cold_tier) == (10_000_000, 1024, "5,5", 1024, 4096, "minibatch", 1, "host")
     if not default:
-        return None
+        return None, None
     path = os.path.join(ROOT, "profiles", "pmc_probe_gather.json")
     try:
         with open(path) as f:
-            return json.load(f).get("hbm_bytes_per_launch")
+            d = json.load(f)
+        return d.get("hbm_bytes_per_launch"), "profiles/pmc_probe_gather.json <- " + str(d.get("source"))
     except Exception:
-        return None
+        return None, None
 
 
 def run_cpu_baseline(args, host_array, batches, fanout, graph=None, seeds_for=None):

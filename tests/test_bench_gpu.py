@@ -31,8 +31,11 @@ def test_bench_single_gpu_contract():
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(r) and r["bound"] == "hbm" and 0 < r["frac"] < 1
     c = d["cpu_baseline"]
     assert {"value", "unit", "cores", "kind", "sample"} <= set(c) and c["kind"] == "port" and c["value"] > 0
+    assert r["traffic_source"] is None          # not the profiled default command line -> no PMC constant is quoted
     e = d["epoch"]
     assert e["serial"]["steps"] == 12 and e["prefetch"]["steps"] == 12 and e["serial"]["ms_per_step"] > 0
+    x = d["config_fanout_10_10"]                # the 10,10 batch shape has an N = 1 origin too
+    assert x["value"] > 0 and x["steps"] == 60 and x["rows_per_step_per_gpu"] > d["config"]["rows_per_step_per_gpu"]
 
 
 def test_bench_two_ranks_on_one_gpu_with_epoch_leg():
@@ -49,3 +52,21 @@ def test_bench_two_ranks_on_one_gpu_with_epoch_leg():
     assert xg["bound"] == "xgmi" and xg["avg_us"] > 0 and xg["remote_bytes_in_per_gpu_per_step"] > 0 and xg["peak"] == 153.0
     x = d["config_fanout_10_10"]
     assert "error" not in x and x["value"] > 0 and x["steps"] == 60 and 0 <= x["hit_ratio"] <= 1
+    assert d["config"]["exchange_transport"] == "torch" and "parity_check" in d["config"]   # gloo hook: no RCCL group -> torch transport
+
+
+def test_bench_rank_failure_is_visible():
+    """A rank-local exception inside an extra leg must not strand the other ranks nor look like a success: rank 0 prints the
+    line with an "error" field and the job ends with a non-zero exit code, quickly."""
+    import time
+    env = dict(os.environ, COALA_BENCH_SINGLE_DEVICE="1", COALA_BENCH_INJECT_FAIL="1:serial")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29573", os.path.join(ROOT, "bench.py"), "--gpus", "2", *SMALL, "--no-fanout-leg"]
+    t0 = time.time()
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode != 0, "a failed rank was reported as success"
+    assert time.time() - t0 < 400
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-1500:] + out.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert "injected failure on rank 1" in d["error"] and d["value"] > 0 and "error" in d["epoch"]

@@ -114,7 +114,10 @@ int coala_shm_open(const char* name, uint64_t bytes, int is_creator, int device,
     int rc = COALA_OK;
     do {
         if (is_creator) { // shared_UVA.cuh:69-76
-            s->fd = shm_open(name, O_CREAT | O_RDWR, S_IRUSR | S_IWUSR);
+            // a fresh object, never the leftovers of a crashed run: the reference memsets the mapping (shared_UVA.cuh:99); a
+            // new POSIX shm object is zero-filled by the kernel, so unlink any stale one and create exclusively
+            (void)shm_unlink(name);
+            s->fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, S_IRUSR | S_IWUSR);
             if (s->fd < 0) { rc = fail(COALA_EIO, "shm_open(%s) failed: %s", name, strerror(errno)); break; }
             if (ftruncate(s->fd, (off_t)bytes) != 0) { rc = fail(COALA_EIO, "ftruncate(%llu) failed: %s", (unsigned long long)bytes, strerror(errno)); break; }
         } else { // shared_UVA.cuh:78-81
@@ -130,8 +133,8 @@ int coala_shm_open(const char* name, uint64_t bytes, int is_creator, int device,
         s->registered = true;
         e = hipHostGetDevicePointer(&s->dev, s->host, 0); // shared_UVA.cuh:94-98
         if (e != hipSuccess) { rc = fail(COALA_EHIP, "hipHostGetDevicePointer failed: %s", hipGetErrorString(e)); break; }
-        // The reference memsets the whole mapping from every rank (shared_UVA.cuh:99); a fresh shm object is already
-        // zero-filled by the kernel, so only the creator touches it (and only to fault pages in lazily on first write).
+        // The reference memsets the whole mapping from every rank (shared_UVA.cuh:99); the creator made a fresh object above,
+        // which the kernel zero-fills page by page on first touch.
     } while (0);
     if (rc != COALA_OK) {
         coala_shm_close(s, is_creator);
@@ -304,6 +307,14 @@ int coala_distributor_create(const int64_t* items, int node_id, int batch_size, 
         if (nd != 2 || shape[0] != d->num_colors || shape[1] != d->topk_k) { rc = fail(COALA_EFORMAT, "%s: shape does not match %s", score_file, topk_file); break; }
         if (off + (size_t)shape[0] * (size_t)shape[1] * 8 > d->score_file.size()) { rc = fail(COALA_EFORMAT, "%s: truncated payload", score_file); break; }
         d->score = reinterpret_cast<const double*>(d->score_file.data() + off);
+        // every neighbour colour indexes the per-domain counter arrays (num_colors + 1 entries) in assign(): validate once
+        // here, so that a malformed or mismatched topk file is a COALA_EFORMAT and not an out-of-bounds read per step
+        for (int64_t k = 0; k < (int64_t)d->num_colors * d->topk_k; ++k)
+            if (d->topk[k] < 0 || d->topk[k] > d->num_colors) {
+                rc = fail(COALA_EFORMAT, "%s: entry %lld is colour %lld, outside [0, %d]", topk_file, (long long)k, (long long)d->topk[k], d->num_colors);
+                break;
+            }
+        if (rc) break;
         d->domain_batch_size = batch_size * local_size;       // :146
         d->global_batch_size = d->domain_batch_size * num_nodes; // :147
     } while (0);

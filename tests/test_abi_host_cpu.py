@@ -144,3 +144,20 @@ def test_distributor_errors(hiplib, tmp_path):
     np.save(tmp_path / "s.npy", np.zeros((3, 2)))
     with pytest.raises(RuntimeError, match="dtype"):
         hiplib.Node_distributor_pybind(items.ctypes.data, 0, 2, 1, 1, str(tmp_path / "c32.npy"), str(tmp_path / "t.npy"), str(tmp_path / "s.npy"))
+
+
+def test_distributor_rejects_out_of_range_topk(hiplib, tmp_path):
+    """neighbour colours from topk.npy index the per-domain counter arrays (num_colors + 1 entries); a value outside
+    [0, num_colors] must be refused when the files are loaded, not read out of bounds on every step."""
+    items = np.arange(10, dtype=np.int64)
+    np.save(tmp_path / "c.npy", np.ones(10, dtype=np.int64))
+    np.save(tmp_path / "s.npy", np.zeros((3, 2)))
+    for bad in (4, -1):
+        tk = np.ones((3, 2), dtype=np.int64)
+        tk[2, 1] = bad
+        np.save(tmp_path / "t.npy", tk)
+        with pytest.raises(RuntimeError, match="outside"):
+            hiplib.Node_distributor_pybind(items.ctypes.data, 0, 2, 1, 1, str(tmp_path / "c.npy"), str(tmp_path / "t.npy"), str(tmp_path / "s.npy"))
+    tk = np.full((3, 2), 3, dtype=np.int64)                  # the largest legal colour
+    np.save(tmp_path / "t.npy", tk)
+    hiplib.Node_distributor_pybind(items.ctypes.data, 0, 2, 1, 1, str(tmp_path / "c.npy"), str(tmp_path / "t.npy"), str(tmp_path / "s.npy"))

@@ -205,3 +205,56 @@ def test_prefetching_loader_can_be_abandoned_mid_epoch(hiplib, oracle, tmp_path)
     del loader
     torch.cuda.synchronize()
     table.close()
+
+
+def test_nvshmem_backend_prefetch_with_slow_consumer(hiplib, oracle, tmp_path):
+    """with the "nvshmem" backend and a prefetching producer, a consumer whose kernels are still reading step t's rows
+    while the producer fetches step t+3 must never see those rows overwritten (the round-1 output ring could be).  The consumer
+    here keeps a long-running kernel between receiving the rows and reading them, and never synchronises per step."""
+    import torch
+    from COALA_GNN import COALA_GNN_DataLoader, MPI_Comm_Manager, Node_Distributor, SSD_INFO
+    from COALA_GNN.sampler import NeighborSampler
+    from COALA_GNN.synthetic import alloc_pinned_table, block_colors, feature_rows_torch, powerlaw_csc
+    n_nodes, dim, batch, fan = 30000, 256, 128, [5, 5]
+    table = alloc_pinned_table(n_nodes, dim, seed=7, device=0)
+    indptr, indices = powerlaw_csc(n_nodes, 8.0, seed=2, device="cuda")
+    color, tk, sc, _ = block_colors(n_nodes, nodes_per_color=512)
+    files = ColorFiles(tmp_path, color, tk, sc)
+    comm = MPI_Comm_Manager(0)
+    comm.initialize_nested_process_group("nvshmem")
+    train_ids = torch.randperm(int(0.6 * n_nodes), generator=torch.Generator().manual_seed(3))[:batch * 21]
+    nd = Node_Distributor(comm, train_ids, batch, files.color_file, files.topk_file, files.score_file, parsing_method="baseline")
+    sampler = NeighborSampler(fan, seed=9)
+    g = sampler.make_graph(indptr, indices)
+    loader = COALA_GNN_DataLoader(SSD_INFO(1, dim * 4, 1024, 0), nd, g, sampler, batch, dim, fan, 2, "cuda:0",
+                                  cache_backend="nvshmem", sim_buf=table, num_rows=n_nodes, prefetch=2)
+    busy = torch.rand((4096, 4096), device="cuda")
+    ok = []
+    for input_nodes, seeds, blocks, feat in loader:
+        for _ in range(6):                       # ~ milliseconds of consumer work queued BEFORE the rows are read
+            busy = (busy @ busy).clamp_(0, 1)
+        ok.append(torch.equal(feat, feature_rows_torch(input_nodes, dim, 7)))   # enqueued behind the busy work, no host sync
+    torch.cuda.synchronize()
+    assert len(ok) == 20 and all(ok)
+    del loader
+    table.close()
+
+
+def test_shm_creator_never_reuses_a_stale_segment(hiplib):
+    """a POSIX shm object left behind by a crashed run must not leak its old contents into a new run."""
+    import ctypes as C
+    import mmap
+    P = hiplib
+    name = f"/coala_stale_test_{os.getpid()}"
+    size = 1 << 20
+    fd = os.open("/dev/shm" + name, os.O_CREAT | os.O_RDWR, 0o600)   # the "crashed run": junk left in the segment
+    os.ftruncate(fd, size)
+    m = mmap.mmap(fd, size)
+    m[:] = b"\xAB" * size
+    m.close()
+    os.close(fd)
+    mgr = P.SharedUVAManager(name, size, 0, 0, 0, local_rank=0, device=0)
+    buf = (C.c_ubyte * size).from_address(mgr.get_host_ptr())
+    assert not any(memoryview(buf)[::4097]) and buf[0] == 0 and buf[size - 1] == 0
+    mgr.cleanup()
+    assert not os.path.exists("/dev/shm" + name)

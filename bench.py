@@ -93,6 +93,7 @@ class RankGuard(object):
         self.deadline, self.what = None, ""
         self.store = dist.distributed_c10d._get_default_store() if world > 1 and dist.is_initialized() else None
         self._stop = threading.Event()
+        self._failing = False
         self._t = None
         if self.store is not None:
             self._t = threading.Thread(target=self._watch, daemon=True)
@@ -109,6 +110,8 @@ class RankGuard(object):
         self._stop.set()
 
     def _leave(self, msg, code):
+        if self.rank != 0:
+            time.sleep(2.0)       # rank 0 prints the line first: the launcher tears every rank down as soon as one has exited
         if self.rank == 0:
             line = dict(self.line) if self.line is not None else {"metric": "feature-gather GB/s", "value": None, "n_gpus": self.world}
             line["error"] = msg
@@ -120,6 +123,8 @@ class RankGuard(object):
 
     def _watch(self):
         while not self._stop.wait(0.5):
+            if self._failing:
+                return            # fail() on the main thread does the leaving
             try:
                 if self.store.check([self.KEY]):
                     self._leave("a rank failed: " + self.store.get(self.KEY).decode(errors="replace"), 4)
@@ -131,12 +136,12 @@ class RankGuard(object):
     def fail(self, exc):
         """Called by the rank that caught an exception: tell the others, then leave non-zero."""
         msg = f"rank {self.rank}: {exc!r}"
-        if self.store is not None:
+        self._failing = True
+        if self.store is not None and self.rank != 0:
             try:
                 self.store.set(self.KEY, msg)
             except Exception:  # noqa: BLE001
                 pass
-            time.sleep(2.0)       # let rank 0's monitor print the line first (it exits the job's rendezvous store with it)
         self._leave(msg, 4)
 
 

@@ -13,7 +13,7 @@ for mode in before after; do
     rm -rf $d
     timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $d -- python3 $R/tools/dist_breakdown.py --mode $mode --reps 20 --pmc > /dev/null 2>&1
     echo "--- rocprofv3 --pmc $c, mode $mode (per step; 21 steps incl. the warm-up serve -> divided by 20: slight over-count)" >> $OUT
-    python3 $R/tools/pmc_by_kernel.py $d $c 20 "anonymous namespace|rocclr_copyBuffer" >> $OUT
+    python3 $R/tools/pmc_by_kernel.py $d $c 20 "anonymous namespace|rocclr_copyBuffer" 200 >> $OUT
     rm -rf $d
   done
 done

@@ -91,7 +91,13 @@ class RankGuard(object):
         self.line = None          # rank 0: the JSON line as far as it is known
         self.partial = None       # dict of the leg in progress (shown under "epoch" on failure)
         self.deadline, self.what = None, ""
-        self.store = dist.distributed_c10d._get_default_store() if world > 1 and dist.is_initialized() else None
+        # an OWN client connection to the job's rendezvous store: the default store's client is one socket behind one mutex, and
+        # a main thread blocked in it (new_group waiting for a rank that has failed) would block this monitor too
+        self.store = None
+        if world > 1 and dist.is_initialized():
+            import datetime
+            self.store = dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500")),
+                                       is_master=False, wait_for_workers=False, timeout=datetime.timedelta(seconds=30))
         self._stop = threading.Event()
         self._failing = False
         self._t = None

@@ -117,6 +117,33 @@ def powerlaw_csc(num_nodes, avg_degree, seed=0, device="cuda", skew=3.0, max_deg
     return indptr, src
 
 
+def community_csc(num_nodes, avg_degree, community=2048, p_in=0.9, seed=0, device="cuda", max_degree=None):
+    """Seeded CSC graph with planted communities (blocks of `community` consecutive ids): an in-neighbour comes from the node's
+    own block with probability p_in, from anywhere otherwise; in-degrees Pareto as in powerlaw_csc.  The power-law generator
+    above has no locality at all, real graphs (IGB, papers100M) do -- this is the shape on which colour-affinity routing has
+    something to find.  Returns int64 (indptr[N+1], indices[E]) on `device`."""
+    g = torch.Generator(device=device).manual_seed(int(seed))
+    n = int(num_nodes)
+    alpha = 2.5
+    xmin = avg_degree * (alpha - 2.0) / (alpha - 1.0)
+    u = torch.rand(n, generator=g, device=device, dtype=torch.float64).clamp_min_(1e-12)
+    deg = (xmin * u.pow(-1.0 / (alpha - 1.0))).floor_().to(torch.int64)
+    cap = int(max_degree) if max_degree else max(64, int(20 * avg_degree))
+    deg.clamp_(min=1, max=cap)
+    indptr = torch.zeros(n + 1, dtype=torch.int64, device=device)
+    torch.cumsum(deg, 0, out=indptr[1:])
+    dst = torch.repeat_interleave(torch.arange(n, device=device, dtype=torch.int64), deg)
+    e = dst.numel()
+    base = (dst // community) * community
+    width = torch.clamp(n - base, max=community)
+    local = base + (torch.rand(e, generator=g, device=device, dtype=torch.float64) * width.to(torch.float64)).to(torch.int64)
+    far = (torch.rand(e, generator=g, device=device, dtype=torch.float64) * n).to(torch.int64).clamp_(max=n - 1)
+    src = torch.where(torch.rand(e, generator=g, device=device) < p_in, local, far)
+    same = src == dst
+    src[same] = torch.where(src[same] + 1 < n, src[same] + 1, src[same] - 1)   # no self loops
+    return indptr, src
+
+
 def block_colors(num_nodes, nodes_per_color=4096, topk=10, seed=0):
     """color[id] = 1 + id // nodes_per_color, with seeded top-k neighbour colours / affinities (numpy, host)."""
     rng = np.random.default_rng(seed)

@@ -65,6 +65,9 @@ def parse_args():
     ap.add_argument("--exchange", type=str, default=None, choices=["torch", "native"],
                     help="N>1: the fused native RCCL call (default whenever the cache group is an RCCL group) or the same sequence "
                          "driven from Python over torch.distributed")
+    ap.add_argument("--no-color-affinity-leg", action="store_true",
+                    help="N=1: skip the extra leg that measures colour-affinity seed routing against baseline striping with two domains on this GPU "
+                         "(tools/color_affinity_probe.py, a child process)")
     ap.add_argument("--no-fanout-leg", action="store_true", help="skip the extra fan-out 10,10 leg (BASELINE.json configs[2] batch shape)")
     ap.add_argument("--cold-tier", type=str, default="host", choices=["host", "hbm"],
                     help="host: pinned host memory, zero-copy over PCIe (the workload BASELINE.json names). hbm: the whole table "
@@ -499,6 +502,11 @@ def _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, dev
                                steps_per_epoch, single_dev)
         if rank == 0:
             line["config_fanout_10_10"] = extra
+    # N=1 only: the reference's distribution comparison (examples/Distribution_compare_script.sh:26-34) on one box -- two domains
+    # x 1 rank on this GPU, real colours from the native colouring tool, node_color against baseline.  A child process: a failure
+    # there is reported in the object and never costs the line.
+    if world == 1 and args.mode == "minibatch" and not args.no_color_affinity_leg:
+        line["color_affinity"] = run_color_affinity_leg()
     guard.disarm()
     if rank == 0:
         print(json.dumps(line), flush=True)
@@ -509,6 +517,29 @@ def _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, dev
     if world > 1:
         guard.close()
         comm.destroy_process_group()
+
+
+def run_color_affinity_leg(timeout_s=400):
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "color_affinity_probe.py")]
+    t0 = time.time()
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        if out.returncode != 0 or not lines:
+            return {"error": f"probe exited with code {out.returncode}: {out.stderr[-300:]}"}
+        d = json.loads(lines[-1])
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)[:300]}
+    keep = ("what", "graph", "nodes", "edges", "dim", "cache_mb_per_domain", "batch", "fanout", "num_colors", "coloring_s",
+            "hit_ratio_all_domains", "fetch_ms_per_step_mean", "note")
+    res = {k: d.get(k) for k in keep}
+    res["steps_per_domain"] = d["baseline"][0]["steps"]
+    res["per_domain_hit_ratio"] = {m: [r["hit_ratio"] for r in d[m]] for m in ("baseline", "node_color")}
+    res["rows_bit_exact_and_batches_partitioned"] = all(r["rows_verified_bit_exact_steps"] > 0 and r["global_batches_partitioned_exactly"]
+                                                        for m in ("baseline", "node_color") for r in d[m])
+    res["leg_seconds"] = round(time.time() - t0, 1)
+    return res
 
 
 def run_fanout_leg(args, comm, graph, table, device, fanout, backend, cold_partitioned, world, rank, train_ids, steps_per_epoch,

@@ -29,19 +29,28 @@ def needs_build():
     return any(os.path.getmtime(p) > t for p in sources() + HEADERS)
 
 
-def build_lib(force=False, verbose=False):
-    """Compile every HIP/C++ source of the product into one shared library for gfx950."""
-    if not force and not needs_build():
-        return LIB_PATH
+DEV_LIB_PATH = os.path.join(LIB_DIR, "libcoala_hip_dev.so")
+
+
+def build_lib(force=False, verbose=False, dev=False):
+    """Compile every HIP/C++ source of the product into one shared library for gfx950.
+    dev=True: libcoala_hip_dev.so with -DCOALA_DEV_KNOBS (launch-geometry knobs from the environment, for tools/k1_insitu.py and
+    friends; select it with COALA_HIP_LIB).  The product library reads no tuning knobs."""
+    out = DEV_LIB_PATH if dev else LIB_PATH
+    if not force and not dev and not needs_build():
+        return out
     os.makedirs(LIB_DIR, exist_ok=True)
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", os.path.join(_ROOT, "include")]
-    cmd += sources() + ["-o", LIB_PATH + ".tmp", "-lrt", "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+    if dev:
+        cmd.append("-DCOALA_DEV_KNOBS")
+        cmd += os.environ.get("COALA_EXTRA_HIPCC_FLAGS", "").split()
+    cmd += sources() + ["-o", out + ".tmp", "-lrt", "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
-    return LIB_PATH
+    os.replace(out + ".tmp", out)
+    return out
 
 
 if __name__ == "__main__":
-    print(build_lib(force="--force" in sys.argv, verbose=True))
+    print(build_lib(force="--force" in sys.argv, verbose=True, dev="--dev" in sys.argv))

@@ -12,11 +12,13 @@
 //                     lane fetches the 32 tags of four sets at once (16 lanes x 2 keys per set), two ballots find the
 //                     matching way, hits are copied HBM line -> output row with nontemporal 16-B loads/stores, 4 rows in
 //                     flight per wave, with the next chunk's ids/tags prefetched behind them.  A miss is pushed on its
-//                     set's chain (atomicExch on the set's own head word, tagged with the batch generation so no clearing
-//                     pass is needed), bumps set_cnt, and marks row_state[position].
+//                     set's chain (ONE atomicExch on the set's own head word, tagged with the batch generation so no
+//                     clearing pass is needed); every row's verdict + chain link is one 4-byte word written per position.
 //   K2 miss_fill    : same chunking.  For a missed row one lane walks the set's chain and counts the misses that precede
 //                     it in batch order: its rank k.  way = (set_cnt_before + k) % 32 -- the reference's round robin
-//                     executed in batch order, for any arrival order of the atomics.  The last writer of a way (the
+//                     executed in batch order, for any arrival order of the atomics; the first-ranked miss of a set advances
+//                     the set's cursor (a generation-tagged 64-bit word, so that late readers still recover the value
+//                     before the batch).  The last writer of a way (the
 //                     "winner") publishes key, colour and line; every miss streams its row from the cold tier (pinned
 //                     host over PCIe, or HBM) into the output.
 #include <hip/hip_runtime.h>
@@ -36,11 +38,14 @@
 namespace {
 
 constexpr uint64_t kEmptyKey = 0xFFFFFFFFFFFFFFFFull; // isolated_cache.h:552
+constexpr uint32_t kLinkMiss = 0x80000000u;            // miss_link: a miss (low 31 bits = chain link)
+constexpr uint32_t kLinkBad = 0x7FFFFFFFu;             // miss_link: id outside [0, num_rows)
 constexpr int kStatBlocks = 2048;                      // upper bound of K2's grid
 
 struct CacheDev {
     uint64_t* keys;        // [sets*32]
-    uint32_t* set_cnt;     // [sets]
+    uint64_t* set_cnt;     // [sets] : (gen << 32) | round-robin cursor.  gen == the current batch's generation: the cursor already
+                           //          includes this batch's misses (K2 advanced it), otherwise it is the value before the batch
     uint32_t* color_meta;  // [sets*32]
     int32_t* color_counters; // [num_colors+1] or null
     const int32_t* node_color; // [num_rows] device copy or null
@@ -56,9 +61,9 @@ struct CacheDev {
     uint32_t distributed;
     uint32_t cold_partitioned; // cold row of id = id / n_gpus
     // per-batch scratch, indexed by the row's POSITION in the batch (no compaction, no list counter)
-    uint8_t* row_state;    // [cap] 0 hit (or idle), 1 miss, 2 rejected id; K1 sets non-zero values, K2 clears them again
     uint64_t* set_head;    // [sets] : (gen << 32) | (position + 1) of the most recently pushed miss of this set
-    uint32_t* miss_next;   // [cap] chain link (position + 1 of the previously pushed miss of the set, 0 = end)
+    uint32_t* miss_link;   // [cap] K1's verdict for every position of the batch, rewritten by every probe (nothing to clear):
+                           //       0 = hit, kLinkBad = rejected id, kLinkMiss | (position + 1 of the previously pushed miss of the set; 0 = end)
     unsigned long long* stats; // [kStatBlocks][2] running sums owned by K2's blocks: misses, rejected ids
 };
 
@@ -145,13 +150,36 @@ struct Geo {
 #define K1_MIN_WAVES 4 // waves per SIMD the register allocator must leave room for
 #endif
 constexpr int kK1Waves = 2; // waves per block (measured: 2048 x 128 threads beats 1024 x 256 and 256 x 1024 by 3-20 %)
+#ifdef COALA_DEV_KNOBS          // development builds only (build.py --dev -> libcoala_hip_dev.so): launch geometry from the environment
+constexpr int kK1MaxWaves = 4;
+#else
+constexpr int kK1MaxWaves = kK1Waves;
+#endif
 
 template <typename V> __device__ __forceinline__ V nt_load(const V* p) { return __builtin_nontemporal_load(p); }
 template <typename V> __device__ __forceinline__ void nt_store(V v, V* p) { __builtin_nontemporal_store(v, p); }
+// K1's row moves (development builds can flip them with -DK1_PLAIN_LOADS / -DK1_PLAIN_STORES: tools/k1_insitu.py)
+template <typename V> __device__ __forceinline__ V k1_load(const V* p) {
+#ifdef K1_PLAIN_LOADS
+    return *p;
+#else
+    return __builtin_nontemporal_load(p);
+#endif
+}
+template <typename V> __device__ __forceinline__ void k1_store(V v, V* p) {
+#ifdef K1_PLAIN_STORES
+    *p = v;
+#else
+    __builtin_nontemporal_store(v, p);
+#endif
+}
 
-template <int CD, int VEC, int NP = 4, bool FULL = false, bool NOMISS = false /* development only: tools/k1_bench */, bool REDIR = false>
-__global__ __launch_bounds__(64 * kK1Waves, K1_MIN_WAVES) void probe_gather_kernel(CacheDev c, const int64_t* __restrict__ idx,
-                                                                    float* __restrict__ out, int64_t n, uint32_t gen, Redirect rd) {
+template <int CD, int VEC, int NP = 4, bool FULL = false, int NOMISS = 0 /* development only: 1 = no miss bookkeeping */, bool REDIR = false>
+__global__ __launch_bounds__(64 * kK1MaxWaves, K1_MIN_WAVES) void probe_gather_kernel(const int64_t* __restrict__ idx, float* __restrict__ out,
+                                                                    int64_t n, uint32_t gen, uint32_t n_blocks, CacheDev c, Redirect rd) {
+    // Argument order and the explicit block count are deliberate: with kernarg preloading (build.py: -amdgpu-kernarg-preload-count)
+    // the leading scalar arguments arrive in SGPRs, and with the compile-time block shape the first id load needs nothing from
+    // the kernarg segment -- the s_loads of the CacheDev fields then overlap that load instead of preceding it.
     // FULL: dim == cache_dim, every lane of a row group moves data -> no per-lane bounds predicate around the row moves
     // REDIR: rows at positions [rd.begin, rd.end) go to rd.out[rd.row_map[..]] (own shard of a distributed fetch); the
     //        destination row travels with the id through the software pipeline, so no load sits in front of the stores
@@ -160,8 +188,13 @@ __global__ __launch_bounds__(64 * kK1Waves, K1_MIN_WAVES) void probe_gather_kern
     constexpr int R = G::R;
     constexpr int TSTEPS = (R + 3) / 4; // tag loads: four sets per wave-wide 16-B load (16 lanes x 2 keys per set)
     const int lane = threadIdx.x & 63;
-    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+#ifdef COALA_DEV_KNOBS
+    const int wpb = (int)(blockDim.x >> 6);
+#else
+    constexpr int wpb = kK1Waves;
+#endif
+    const int64_t wave = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)n_blocks * wpb;
     const int64_t n_chunks = (n + R - 1) / R;
     const uint32_t nunits = c.dim / VEC; // accesses per output row
 
@@ -245,12 +278,12 @@ __global__ __launch_bounds__(64 * kK1Waves, K1_MIN_WAVES) void probe_gather_kern
             }
         }
         // ---- misses: push the row on its set's chain (the old head comes back behind the row loads)
-        const bool i_miss = !NOMISS && lane < R && ((missmask >> lane) & 1);
+        const bool i_miss = NOMISS != 1 && lane < R && ((missmask >> lane) & 1);
         unsigned long long prev = 0;
         if (i_miss) {
             const unsigned long long tag = ((unsigned long long)gen << 32) | (unsigned long long)(base + lane + 1);
             prev = atomicExch(reinterpret_cast<unsigned long long*>(c.set_head + my_set), tag);
-            atomicAdd(c.set_cnt + my_set, 1u); // isolated_cache.h:203 set_cnt_[set]++ (no return value needed)
+            // (the set's round-robin cursor, isolated_cache.h:203, is advanced by K2: an atomicAdd here cost 1.2 us per launch)
         }
         // ids two chunks ahead (consumed by load_tags in the NEXT iteration: a full row round trip of slack)
         const Ids ids_next2 = load_ids(chunk + 2 * n_waves);
@@ -270,7 +303,7 @@ __global__ __launch_bounds__(64 * kK1Waves, K1_MIN_WAVES) void probe_gather_kern
 #pragma unroll
             for (int v = 0; v < G::VPL; ++v) {
                 const uint32_t u = v * G::LPR + l_in;
-                if (h && (FULL || u < nunits)) val[p][v] = nt_load(src + u);
+                if (h && (FULL || u < nunits)) val[p][v] = k1_load(src + u);
             }
         }
         tags = load_tags(ids_next);
@@ -289,25 +322,67 @@ __global__ __launch_bounds__(64 * kK1Waves, K1_MIN_WAVES) void probe_gather_kern
             for (int v = 0; v < G::VPL; ++v) {
                 const uint32_t u = v * G::LPR + l_in;
                 if (FULL || u < nunits) {
-                    if (h) nt_store(val[p][v], dst + u);
+                    if (h) k1_store(val[p][v], dst + u);
                     else if (bad) dst[u] = V(0.0f); // rejected id: zero row (kept inline: hoisting it out costs 12 VGPRs and 10 % speed)
                 }
             }
         }
-        // ---- verdict for K2: only rows that are not hits write anything (row_state is zero between batches)
-        if (i_miss) {
-            c.row_state[base + lane] = 1;
-            c.miss_next[base + lane] = ((uint32_t)(prev >> 32) == gen) ? (uint32_t)prev : 0u;
-        } else if (!NOMISS && lane < R && ((badmask >> lane) & 1)) {
-            c.row_state[base + lane] = 2;
+        // ---- verdict for K2: one word per position, written for EVERY row of the chunk (one 4-byte store per lane q < R), so the
+        //      array never needs clearing between batches
+        if (NOMISS != 1 && lane < R && base + lane < n) {
+            uint32_t w = 0u;
+            if (i_miss) w = kLinkMiss | (((uint32_t)(prev >> 32) == gen) ? (uint32_t)prev : 0u);
+            else if ((badmask >> lane) & 1) w = kLinkBad;
+            c.miss_link[base + lane] = w;
         }
     }
 }
 
+#ifdef COALA_DEV_KNOBS
+// Development only (tools/k1_insitu.py --stages): the prologue of K1 cut short after each link of its dependency chain, one chunk
+// per wave, to see where the fixed cost of a launch goes.  STAGE 0: nothing; 1: ids; 2: ids + tags + ballots; 3: + the line loads
+// of the hit rows (no stores).
+template <int STAGE>
+__global__ __launch_bounds__(256, K1_MIN_WAVES) void k1_stage_kernel(const int64_t* __restrict__ idx, float* __restrict__ out, int64_t n,
+                                                                     CacheDev c) {
+    if (STAGE == 0) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t chunk = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t i_l = chunk * 4 + (lane >> 4);
+    const uint64_t id = (i_l < n) ? (uint64_t)idx[i_l] : 0;
+    if (STAGE == 1) {
+        if (id == 0x7FFFFFFFFFFFFFF1ull) out[0] = 1.f;
+        return;
+    }
+    const bool ok = i_l < n && id < c.num_rows;
+    const uint64_t set = ok ? set_of(c, id) : 0;
+    vu64x2 kk = vu64x2{kEmptyKey, kEmptyKey};
+    if (ok) kk = *reinterpret_cast<const vu64x2*>(c.keys + set * COALA_WAYS + (lane & 15) * 2);
+    const uint64_t m0 = __ballot(ok && kk.x == id), m1 = __ballot(ok && kk.y == id);
+    if (STAGE == 2) {
+        if ((m0 ^ m1) == 0x123456789ABCDEFull) out[0] = 1.f;
+        return;
+    }
+    vfloat4 acc = vfloat4{0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t a = (uint32_t)(m0 >> (16 * q)) & 0xFFFFu, b = (uint32_t)(m1 >> (16 * q)) & 0xFFFFu;
+        if (a | b) {
+            const int j = __builtin_ctz(a | b);
+            const uint32_t way = 2 * j + (((a >> j) & 1) ? 0 : 1);
+            const uint64_t set_q = readlane64(set, 16 * q);
+            const vfloat4* src = reinterpret_cast<const vfloat4*>(c.lines + (set_q * COALA_WAYS + way) * 1024);
+            for (int v = 0; v < 4; ++v) acc += nt_load(src + v * 64 + lane);
+        }
+    }
+    if (acc.x == 123456.789f) out[0] = acc.y;
+}
+#endif
+
 // ---------------------------------------------------------------------------------------------------------- K2
 // Rank + fill.  isolated_cache.h:197-210 (round robin in batch order), :417-474 (miss path), :323-331 (cold read).
-// Hazard-free in ONE kernel because K1 already advanced set_cnt: set_cnt_before = set_cnt - (misses of the set), every
-// way touched in this batch has exactly one winner, and only winners touch keys / color_meta / lines.
+// Hazard-free in ONE kernel: every reader of a set's cursor recovers the value before the batch whether or not the set's
+// first-ranked miss has already advanced it (generation tag), every way touched in this batch has exactly one winner, and only
+// winners touch keys / color_meta / lines.
 __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src) {
     const uint32_t lo = __shfl((int)(uint32_t)v, src), hi = __shfl((int)(uint32_t)(v >> 32), src);
     return ((uint64_t)hi << 32) | lo;
@@ -315,7 +390,7 @@ __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src) {
 
 template <int CD, int VEC, bool REDIR = false, int NP = 4>
 __global__ __launch_bounds__(256) void miss_fill_kernel(CacheDev c, const int64_t* __restrict__ idx, float* __restrict__ out,
-                                                        int tile_rows, RangeSet rs, Redirect rd) {
+                                                        int tile_rows, uint32_t gen, RangeSet rs, Redirect rd) {
     // Works on the batch positions of `rs` (the whole batch = one range, or the slices of a serve split into several fills),
     // walked as one dense virtual index space.  A wave reads the verdicts of tile_rows rows at once (one byte per lane;
     // tile_rows = R or 64) and then works through the tile chunk by chunk (R rows), skipping chunks without a miss on a scalar
@@ -342,8 +417,9 @@ __global__ __launch_bounds__(256) void miss_fill_kernel(CacheDev c, const int64_
       for (int u = 0; u < U; ++u) {
           const int64_t tile = tile0 + u * n_waves;
           const uint32_t p = (tile < n_tiles && lane < tile_rows) ? pos_of(rs, (uint32_t)(tile * tile_rows + lane)) : 0xFFFFFFFFu;
-          const uint8_t v = (p != 0xFFFFFFFFu) ? c.row_state[p] : (uint8_t)0;
-          st_pack |= (uint32_t)v << (8 * u);
+          const uint32_t w = (p != 0xFFFFFFFFu) ? c.miss_link[p] : 0u;
+          const uint32_t v = (w == 0u) ? 0u : ((w & kLinkMiss) ? 1u : 2u);
+          st_pack |= v << (8 * u);
       }
       if (!__ballot(st_pack != 0)) continue; // nothing but hits in these U tiles
 #pragma nounroll
@@ -353,7 +429,6 @@ __global__ __launch_bounds__(256) void miss_fill_kernel(CacheDev c, const int64_
         if (!__ballot(st != 0)) continue;
         // a lane with a verdict has a valid position (recomputed: cheaper than keeping U of them alive across the loop)
         const uint32_t pos_l = st ? pos_of(rs, (uint32_t)((tile0 + u * n_waves) * tile_rows + lane)) : 0u;
-        if (st) c.row_state[pos_l] = 0; // leave the array clean for the next batch
         my_miss += (st == 1);
         my_bad += (st == 2);
         if (!tile_mask) continue;
@@ -376,9 +451,12 @@ __global__ __launch_bounds__(256) void miss_fill_kernel(CacheDev c, const int64_
                     const uint32_t p2 = cur - 1;
                     ++total;
                     rank += (p2 < pos_l) ? 1u : 0u;
-                    cur = c.miss_next[p2];
+                    cur = c.miss_link[p2] & ~kLinkMiss;
                 }
-                const uint32_t cnt0 = c.set_cnt[set] - total;                       // value before this batch
+                // the cursor before this batch: the set's first-ranked miss advances it below, tagged with the generation
+                const uint64_t cv = __hip_atomic_load(c.set_cnt + set, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t cnt0 = ((uint32_t)(cv >> 32) == gen) ? (uint32_t)cv - total : (uint32_t)cv;
+                if (rank == 0) __hip_atomic_store(c.set_cnt + set, ((uint64_t)gen << 32) | (uint32_t)(cnt0 + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const uint32_t way = (cnt0 + rank) & (COALA_WAYS - 1);              // isolated_cache.h:203
                 slot_l = (uint32_t)(set * COALA_WAYS) + way;
                 win_l = (rank + COALA_WAYS >= total) ? 1u : 0u;                     // nobody later in the batch lands here
@@ -622,7 +700,9 @@ struct coala_cache {
     Redirect open_redirect{0, 0, nullptr, nullptr};       // the open batch's redirect (set by the probe, reused by its fills)
     int k2_tile_rows = 0;                 // rows per verdict tile of K2: 64 for a host cold tier, 0 = one chunk (COALA_K2_TILE_ROWS)
     int k1_passes = 4;                    // rows(-pairs) in flight per wave in K1 (tunable: COALA_K1_PASSES = 2 | 4)
-    int k1_grid_cap = 256 * 8;            // K1 blocks (tunable: COALA_K1_GRID)
+    int k1_grid_cap = 8192;               // K1 blocks: one chunk per wave up to 65,536 rows (measured in situ, 28.5 k rows at 32 % hits: 2048 -> 22.3 us,
+                                          // 4096 -> 20.7, 8192 -> 20.6; all-hit 36,864 rows: 53.8 / 53.1 / 51.4 us; tools/k1_insitu.py)
+    int k1_waves = kK1Waves;              // K1 waves per block
     uint64_t rows_total = 0;              // rows submitted since the last stats reset (hits = rows - misses - rejected)
     uint64_t cum_hit = 0, cum_miss = 0;   // totals folded in whenever coala_cache_stats resets the device counters
     uint64_t prof_hit0 = 0, prof_miss0 = 0; // totals at the last profile reset
@@ -645,15 +725,9 @@ int ensure_scratch(coala_cache* h, uint64_t n, hipStream_t s) {
     HIPCHK(hipStreamSynchronize(s));
     uint64_t cap = h->cap ? h->cap : 1024;
     while (cap < n) cap *= 2;
-    if (h->d.miss_next) HIPCHK(hipFree(h->d.miss_next));
-    h->d.miss_next = nullptr;
-    HIPCHK(hipMalloc((void**)&h->d.miss_next, cap * sizeof(uint32_t)));
-    if (h->d.row_state) HIPCHK(hipFree(h->d.row_state));
-    h->d.row_state = nullptr;
-    HIPCHK(hipMalloc((void**)&h->d.row_state, cap));
-    // K1 marks non-hits, K2 clears them again.  On the CALLER's stream: a null-stream memset is not ordered against a
-    // non-blocking stream and could land after K1's marks (seen as unfilled rows on the first batch of a handle).
-    HIPCHK(hipMemsetAsync(h->d.row_state, 0, cap, s));
+    if (h->d.miss_link) HIPCHK(hipFree(h->d.miss_link));
+    h->d.miss_link = nullptr;
+    HIPCHK(hipMalloc((void**)&h->d.miss_link, cap * sizeof(uint32_t))); // written by every probe before any fill reads it
     h->cap = cap;
     return COALA_OK;
 }
@@ -802,13 +876,13 @@ int coala_cache_create(const coala_cache_config_t* cfg, coala_cache_t** out) {
     };
     do {
         if ((rc = alloc((void**)&d.keys, slots * 8))) break;
-        if ((rc = alloc((void**)&d.set_cnt, sets * 4))) break;
+        if ((rc = alloc((void**)&d.set_cnt, sets * 8))) break;
         if ((rc = alloc((void**)&d.color_meta, slots * 4))) break;
         if ((rc = alloc((void**)&d.set_head, sets * 8))) break;
         if ((rc = alloc((void**)&d.stats, kStatBlocks * 2 * 8))) break;
         if ((rc = alloc((void**)&d.lines, slots * (uint64_t)cd * 4))) break;
         if ((rc = alloc((void**)&h->route_bases, 65 * 8))) break;
-        if (hipMemset(d.keys, 0xFF, slots * 8) != hipSuccess || hipMemset(d.set_cnt, 0, sets * 4) != hipSuccess ||
+        if (hipMemset(d.keys, 0xFF, slots * 8) != hipSuccess || hipMemset(d.set_cnt, 0, sets * 8) != hipSuccess ||
             hipMemset(d.color_meta, 0, slots * 4) != hipSuccess || hipMemset(d.set_head, 0, sets * 8) != hipSuccess ||
             hipMemset(d.stats, 0, kStatBlocks * 2 * 8) != hipSuccess) {
             rc = fail(COALA_EHIP, "hipMemset failed");
@@ -835,8 +909,11 @@ int coala_cache_create(const coala_cache_config_t* cfg, coala_cache_t** out) {
             d.node_color = h->node_color_dev;
         }
         h->gen = 0;
+#ifdef COALA_DEV_KNOBS
         if (const char* e = getenv("COALA_K1_PASSES")) h->k1_passes = atoi(e) == 2 ? 2 : 4;
         if (const char* e = getenv("COALA_K1_GRID")) { int g = atoi(e); if (g >= 1 && g <= 65535) h->k1_grid_cap = g; }
+        if (const char* e = getenv("COALA_K1_WAVES")) { int w = atoi(e); if (w == 1 || w == 2 || w == 4) h->k1_waves = w; }
+#endif
         {
             hipPointerAttribute_t attr;
             const bool host_tier = hipPointerGetAttributes(&attr, cfg->cold_table) == hipSuccess && attr.type == hipMemoryTypeHost;
@@ -848,8 +925,10 @@ int coala_cache_create(const coala_cache_config_t* cfg, coala_cache_t** out) {
             const int host_blocks = std::min(64, std::max(16, 16 * 1024 / (int)d.cache_dim));
             h->k2_grid_cap = host_tier ? host_blocks : kStatBlocks;
             h->k2_tile_rows = host_tier ? 64 : 0;
+#ifdef COALA_DEV_KNOBS
             if (const char* e = getenv("COALA_K2_TILE_ROWS")) { int t = atoi(e); if (t == 0 || t == 8 || t == 16 || t == 32 || t == 64) h->k2_tile_rows = t; }
             if (const char* e = getenv("COALA_K2_GRID")) { int g = atoi(e); if (g >= 1 && g <= kStatBlocks) h->k2_grid_cap = g; }
+#endif
         }
         if (cfg->max_batch) rc = ensure_scratch(h, cfg->max_batch, nullptr);
     } while (0);
@@ -869,8 +948,8 @@ int coala_cache_destroy(coala_cache_t* h) {
     drain_events(h);
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
     CacheDev& d = h->d;
-    void* ptrs[] = {d.keys, d.set_cnt, d.color_meta, d.set_head, d.row_state, d.stats, d.lines, d.color_counters,
-                    h->node_color_dev, d.miss_next,
+    void* ptrs[] = {d.keys, d.set_cnt, d.color_meta, d.set_head, d.stats, d.lines, d.color_counters,
+                    h->node_color_dev, d.miss_link,
                     h->wave_counts, h->route_bases};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -899,8 +978,8 @@ static int read_feature_impl(coala_cache_t* h, float* out, const int64_t* idx, i
     if (!h) return fail(COALA_EINVAL, "null handle");
     if (n < 0 || n > 0x7FFFFFFFll) return fail(COALA_EINVAL, "n=%lld out of range", (long long)n);
     if (phases & kPhaseProbe) {
-        // a batch that was probed and not completely filled still owns row_state and the per-set miss chains: a second
-        // probe on top of it would leave stale verdicts behind (K2 is what clears them)
+        // a batch that was probed and not completely filled still owns the verdict words and the per-set miss chains: a second
+        // probe on top of it would overwrite them under the pending fills
         if (h->open_batch_rows >= 0)
             return fail(COALA_EINVAL, "a batch of %lld rows is still open (%lld filled): finish its serve_fill calls or call coala_cache_serve_abort",
                         (long long)h->open_batch_rows, (long long)h->open_filled_rows);
@@ -948,8 +1027,9 @@ static int read_feature_impl(coala_cache_t* h, float* out, const int64_t* idx, i
     int rc = ensure_scratch(h, (uint64_t)n, s);
     if (rc) return rc;
     if (phases & kPhaseProbe) {
-        if (++h->gen == 0) { // generation wrapped: clear the chain heads once
+        if (++h->gen == 0) { // generation wrapped: clear the chain heads and the generation tags of the cursors once
             HIPCHK(hipMemsetAsync(h->d.set_head, 0, h->d.num_sets * 8, s));
+            HIPCHK(hipMemset2DAsync(reinterpret_cast<char*>(h->d.set_cnt) + 4, 8, 0, 4, h->d.num_sets, s));
             h->gen = 1;
         }
         if (!(phases & kPhaseFill)) { // a probe alone leaves the batch open for its fills
@@ -973,18 +1053,18 @@ static int read_feature_impl(coala_cache_t* h, float* out, const int64_t* idx, i
         if (phases & kPhaseProbe) {
             ProfScope ps(h, s, 0, (uint64_t)n);
             const bool full = (VEC == 4) && ((int)d.dim == CD);
-            const dim3 grid(grid_for(chunks, kK1Waves, h->k1_grid_cap)), block(64 * kK1Waves);
+            const dim3 grid(grid_for(chunks, h->k1_waves, h->k1_grid_cap)), block(64 * h->k1_waves);
             if (redir) {
-                hipLaunchKernelGGL((probe_gather_kernel<CD, VEC, 4, false, false, true>), grid, block, 0, s, d, idx, out, n, gen, rd);
+                hipLaunchKernelGGL((probe_gather_kernel<CD, VEC, 4, false, 0, true>), grid, block, 0, s, idx, out, n, gen, grid.x, d, rd);
             } else if (h->k1_passes == 2) {
                 using G2 = Geo<CD, VEC, 2>;
                 const int64_t chunks2 = (n + G2::R - 1) / G2::R;
-                hipLaunchKernelGGL((probe_gather_kernel<CD, VEC, 2, false>), dim3(grid_for(chunks2, kK1Waves, h->k1_grid_cap)), block, 0, s,
-                                   d, idx, out, n, gen, rd);
+                const dim3 grid2(grid_for(chunks2, h->k1_waves, h->k1_grid_cap));
+                hipLaunchKernelGGL((probe_gather_kernel<CD, VEC, 2, false>), grid2, block, 0, s, idx, out, n, gen, grid2.x, d, rd);
             } else if (full) {
-                hipLaunchKernelGGL((probe_gather_kernel<CD, VEC, 4, true>), grid, block, 0, s, d, idx, out, n, gen, rd);
+                hipLaunchKernelGGL((probe_gather_kernel<CD, VEC, 4, true>), grid, block, 0, s, idx, out, n, gen, grid.x, d, rd);
             } else {
-                hipLaunchKernelGGL((probe_gather_kernel<CD, VEC, 4, false>), grid, block, 0, s, d, idx, out, n, gen, rd);
+                hipLaunchKernelGGL((probe_gather_kernel<CD, VEC, 4, false>), grid, block, 0, s, idx, out, n, gen, grid.x, d, rd);
             }
         }
         if ((phases & kPhaseFill) && fill_rows > 0) {
@@ -994,8 +1074,8 @@ static int read_feature_impl(coala_cache_t* h, float* out, const int64_t* idx, i
                 ProfScope ps(h, s, 2, 0);
                 const int64_t tiles = ((int64_t)rs.total + tile_rows - 1) / tile_rows;
                 const dim3 grid(grid_for(tiles, 4, h->k2_grid_cap));
-                if (redir) hipLaunchKernelGGL((miss_fill_kernel<CD, VEC, true>), grid, dim3(256), 0, s, d, idx, out, tile_rows, rs, rd);
-                else hipLaunchKernelGGL((miss_fill_kernel<CD, VEC, false>), grid, dim3(256), 0, s, d, idx, out, tile_rows, rs, rd);
+                if (redir) hipLaunchKernelGGL((miss_fill_kernel<CD, VEC, true>), grid, dim3(256), 0, s, d, idx, out, tile_rows, gen, rs, rd);
+                else hipLaunchKernelGGL((miss_fill_kernel<CD, VEC, false>), grid, dim3(256), 0, s, d, idx, out, tile_rows, gen, rs, rd);
                 return COALA_OK;
             });
         }
@@ -1046,9 +1126,9 @@ int coala_cache_serve_abort(coala_cache_t* h, void* stream) {
     if (!h) return fail(COALA_EINVAL, "null handle");
     if (h->open_batch_rows < 0) return COALA_OK;
     HIPCHK(hipSetDevice(h->cfg.device));
-    // the probe already advanced the round-robin cursors of the sets that missed: legal (the cursor only picks the next victim);
-    // what must not survive is the verdict array, which only a fill clears
-    HIPCHK(hipMemsetAsync(h->d.row_state, 0, h->cap, (hipStream_t)stream));
+    // nothing on the device to undo: the next probe starts a new generation and rewrites every verdict word it will read; rows
+    // whose fill already ran are cached, the others are not
+    (void)stream;
     h->open_batch_rows = -1;
     h->open_filled.clear();
     h->open_filled_rows = 0;
@@ -1125,6 +1205,26 @@ int coala_cache_scatter(coala_cache_t* h, float* out, const float* src, const in
     return coala_cache_scatter_ranges(h, out, src, map, &b, &n, 1, stream);
 }
 
+#ifdef COALA_DEV_KNOBS
+int coala_dev_k1_stage(coala_cache_t* h, float* out, const int64_t* idx, int64_t n, int stage, void* stream) { // not part of the ABI
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)((n + 7) / 8)), block(128);
+    switch (stage) {
+        case 0: hipLaunchKernelGGL(k1_stage_kernel<0>, grid, block, 0, s, idx, out, n, h->d); break;
+        case 1: hipLaunchKernelGGL(k1_stage_kernel<1>, grid, block, 0, s, idx, out, n, h->d); break;
+        case 2: hipLaunchKernelGGL(k1_stage_kernel<2>, grid, block, 0, s, idx, out, n, h->d); break;
+        case 3: hipLaunchKernelGGL(k1_stage_kernel<3>, grid, block, 0, s, idx, out, n, h->d); break;
+        case 4: // the product kernel without the miss bookkeeping (hits copied, misses ignored)
+            hipLaunchKernelGGL((probe_gather_kernel<1024, 4, 4, true, 1>), grid, block, 0, s, idx, out, n, 0xFFFFFFF0u, grid.x, h->d, Redirect{0, 0, nullptr, nullptr});
+            break;
+        default: // the product kernel itself on a generation nobody consumes
+            hipLaunchKernelGGL((probe_gather_kernel<1024, 4, 4, true, 0>), grid, block, 0, s, idx, out, n, 0xFFFFFFF1u, grid.x, h->d, Redirect{0, 0, nullptr, nullptr});
+            break;
+    }
+    return COALA_OK;
+}
+#endif
+
 int coala_cache_color_counts(coala_cache_t* h, int32_t* dst, int32_t n_entries, void* stream) {
     if (!h || !dst) return fail(COALA_EINVAL, "null argument");
     if (n_entries < 0 || n_entries > h->cfg.num_colors + 1) return fail(COALA_EINVAL, "n_entries=%d exceeds num_colors+1=%d", n_entries, h->cfg.num_colors + 1);
@@ -1173,7 +1273,7 @@ int coala_cache_dump(coala_cache_t* h, uint64_t* keys, uint32_t* set_cnt, uint32
     const uint64_t slots = h->d.num_sets * COALA_WAYS;
     HIPCHK(hipStreamSynchronize(s));
     if (keys) HIPCHK(hipMemcpy(keys, h->d.keys, slots * 8, hipMemcpyDeviceToHost));
-    if (set_cnt) HIPCHK(hipMemcpy(set_cnt, h->d.set_cnt, h->d.num_sets * 4, hipMemcpyDeviceToHost));
+    if (set_cnt) HIPCHK(hipMemcpy2D(set_cnt, 4, h->d.set_cnt, 8, 4, h->d.num_sets, hipMemcpyDeviceToHost)); // the cursors without their generation tags
     if (color_meta) HIPCHK(hipMemcpy(color_meta, h->d.color_meta, slots * 4, hipMemcpyDeviceToHost));
     return COALA_OK;
 }

@@ -10,7 +10,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SMALL = ["--rows", "300000", "--prewarm", "20", "--steps", "10", "--warmup", "3", "--cache-mb", "256", "--epoch-steps", "12",
-         "--cpu-baseline-batches", "2", "--allhit-launches", "5"]
+         "--cpu-baseline-batches", "2", "--allhit-launches", "5", "--no-color-affinity-leg"]
 REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
             "dtype", "data", "config", "roofline", "cpu_baseline"}
 
@@ -70,3 +70,20 @@ def test_bench_rank_failure_is_visible():
     assert len(lines) == 1, out.stdout[-1500:] + out.stderr[-3000:]
     d = json.loads(lines[0])
     assert "injected failure on rank 1" in d["error"] and d["value"] > 0 and "error" in d["epoch"]
+
+
+def test_color_affinity_probe_two_domains():
+    """f-3: two domains x 1 rank on GPU 0, real colours from the native colouring tool on a planted-community graph; node_color and
+    baseline must both deliver the table's rows bit-exact and partition every global batch exactly; the hit ratios are reported."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "color_affinity_probe.py"), "--nodes", "150000", "--dim", "128",
+                          "--cache-mb", "8", "--batch", "256", "--max-steps", "60", "--community", "512"],
+                         capture_output=True, text=True, timeout=600)
+    d = _line(out)
+    for mode in ("baseline", "node_color"):
+        assert len(d[mode]) == 2
+        for r in d[mode]:
+            assert r["steps"] == 60 and r["rows_verified_bit_exact_steps"] == 5 and r["global_batches_partitioned_exactly"] is True
+            assert 0 < r["hit_ratio"] < 1 and r["fetch_ms_per_step"] > 0
+    assert d["num_colors"] > 10
+    h = d["hit_ratio_all_domains"]
+    assert h["node_color"] > h["baseline"] - 0.01, h     # on a graph with communities affinity routing must not lose

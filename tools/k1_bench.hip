@@ -96,10 +96,8 @@ __global__ __launch_bounds__(1024) void probe_gather_v2(CacheDev c, const int64_
                 } else if (EXTRA && ((badmask >> p) & 1)) dst[v * 64 + lane] = V(0.0f);
         }
         if (EXTRA >= 2) {
-            if (i_miss) {
-                c.row_state[base + lane] = 1;
-                c.miss_next[base + lane] = ((uint32_t)(prev >> 32) == gen) ? (uint32_t)prev : 0u;
-            } else if (lane < R && ((badmask >> lane) & 1)) c.row_state[base + lane] = 2;
+            if (i_miss) c.miss_link[base + lane] = kLinkMiss | (((uint32_t)(prev >> 32) == gen) ? (uint32_t)prev : 0u);
+            else if (lane < R && ((badmask >> lane) & 1)) c.miss_link[base + lane] = kLinkBad;
         }
     }
 }
@@ -218,23 +216,23 @@ int main(int argc, char** argv) {
         vs.push_back({"prod P" + std::to_string(np) + " g" + std::to_string(grid) + " b" + std::to_string(block), [=](hipStream_t s) {
             // K1 alone: with misses it leaves marks/chains behind that K2 would consume; harmless for timing (fresh generation)
             ++fake_gen;
-            if (dim == 1024 && np == 4) hipLaunchKernelGGL((probe_gather_kernel<1024, 4, 4, false>), dim3(grid), dim3(block), 0, s, h->d, d_ids, out, n, fake_gen);
-            else if (dim == 1024 && np == 6) hipLaunchKernelGGL((probe_gather_kernel<1024, 4, 4, true, true>), dim3(grid), dim3(block), 0, s, h->d, d_ids, out, n, fake_gen);
-            else if (dim == 1024 && np == 5) hipLaunchKernelGGL((probe_gather_kernel<1024, 4, 4, true>), dim3(grid), dim3(block), 0, s, h->d, d_ids, out, n, fake_gen);
-            else if (dim == 128 && np == 5) hipLaunchKernelGGL((probe_gather_kernel<128, 4, 4, true>), dim3(grid), dim3(block), 0, s, h->d, d_ids, out, n, fake_gen);
-            else if (dim == 1024 && np == 2) hipLaunchKernelGGL((probe_gather_kernel<1024, 4, 2>), dim3(grid), dim3(block), 0, s, h->d, d_ids, out, n, fake_gen);
-            else if (dim == 128 && np == 4) hipLaunchKernelGGL((probe_gather_kernel<128, 4, 4>), dim3(grid), dim3(block), 0, s, h->d, d_ids, out, n, fake_gen);
-            else if (dim == 128 && np == 2) hipLaunchKernelGGL((probe_gather_kernel<128, 4, 2>), dim3(grid), dim3(block), 0, s, h->d, d_ids, out, n, fake_gen);
+            if (dim == 1024 && np == 4) hipLaunchKernelGGL((probe_gather_kernel<1024, 4, 4, false, 0>), dim3(grid), dim3(block), 0, s, d_ids, out, n, fake_gen, (uint32_t)grid, h->d, Redirect{0, 0, nullptr, nullptr});
+            else if (dim == 1024 && np == 6) hipLaunchKernelGGL((probe_gather_kernel<1024, 4, 4, true, 1>), dim3(grid), dim3(block), 0, s, d_ids, out, n, fake_gen, (uint32_t)grid, h->d, Redirect{0, 0, nullptr, nullptr});
+            else if (dim == 1024 && np == 5) hipLaunchKernelGGL((probe_gather_kernel<1024, 4, 4, true>), dim3(grid), dim3(block), 0, s, d_ids, out, n, fake_gen, (uint32_t)grid, h->d, Redirect{0, 0, nullptr, nullptr});
+            else if (dim == 128 && np == 5) hipLaunchKernelGGL((probe_gather_kernel<128, 4, 4, true>), dim3(grid), dim3(block), 0, s, d_ids, out, n, fake_gen, (uint32_t)grid, h->d, Redirect{0, 0, nullptr, nullptr});
+            else if (dim == 1024 && np == 2) hipLaunchKernelGGL((probe_gather_kernel<1024, 4, 2>), dim3(grid), dim3(block), 0, s, d_ids, out, n, fake_gen, (uint32_t)grid, h->d, Redirect{0, 0, nullptr, nullptr});
+            else if (dim == 128 && np == 4) hipLaunchKernelGGL((probe_gather_kernel<128, 4, 4>), dim3(grid), dim3(block), 0, s, d_ids, out, n, fake_gen, (uint32_t)grid, h->d, Redirect{0, 0, nullptr, nullptr});
+            else if (dim == 128 && np == 2) hipLaunchKernelGGL((probe_gather_kernel<128, 4, 2>), dim3(grid), dim3(block), 0, s, d_ids, out, n, fake_gen, (uint32_t)grid, h->d, Redirect{0, 0, nullptr, nullptr});
         }});
     };
-    add_prod(2048, 128, 4); add_prod(2048, 128, 5); add_prod(2048, 128, 6);
+    add_prod(2048, 128, 4); add_prod(2048, 128, 5); add_prod(8192, 128, 5); add_prod(2048, 128, 6); add_prod(8192, 128, 6);
     if (hit_pct == 100) {
         if (dim == 1024) {
             auto add_v2 = [&](const char* nm, auto kern, int grid, int block) {
                 vs.push_back({std::string(nm) + " g" + std::to_string(grid) + " b" + std::to_string(block),
                               [=](hipStream_t s) { hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, s, h->d, d_ids, out, n, 1u); }});
             };
-            for (int g : {2048}) {
+            for (int g : {2048, 8192}) {
                 add_v2("v3 lds-dma+nt R4", probe_gather_lds<4, true>, g, 128);
             }
             for (auto gb : {std::pair<int, int>{2048, 128}}) {

@@ -1,0 +1,115 @@
+#!/usr/bin/env python3
+"""probe_gather_kernel IN SITU: the default bench workload (IGB-medium shape, fan-out 5,5, isolated 4 GiB cache, pinned-host cold
+tier), one cache handle per variant (COALA_K1_* environment knobs are read at handle creation), 400 warm-up minibatches, then
+the kernel's average duration over 200 timed minibatches by HIP events (COALA_FLAG_PROFILE) -- i.e. with the cold fill of the
+previous step in front of every launch, which the tools/k1_bench micro-benchmark does not have.
+
+  python tools/k1_insitu.py "GRID=2048" "GRID=1024" "GRID=2048,PASSES=2" ...      (knob list per variant, comma separated)"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "coala-gnn_amd"))
+import importlib.util  # noqa: E402
+_spec = importlib.util.spec_from_file_location("coala_build", os.path.join(ROOT, "coala-gnn_amd", "build.py"))
+_bm = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(_bm)
+if not os.path.exists(_bm.DEV_LIB_PATH) or os.path.getmtime(_bm.DEV_LIB_PATH) < max(os.path.getmtime(p) for p in _bm.sources() + _bm.HEADERS):
+    _bm.build_lib(dev=True)
+os.environ["COALA_HIP_LIB"] = os.environ.get("K1_LIB", _bm.DEV_LIB_PATH)   # the development build: launch-geometry knobs from the environment
+import torch  # noqa: E402
+import COALA_GNN_Pybind as P  # noqa: E402
+from COALA_GNN.synthetic import PinnedFeatureTable, fill_table, powerlaw_csc  # noqa: E402
+from COALA_GNN.sampler import NeighborSampler  # noqa: E402
+
+rows, dim, batch, cache_mb = int(os.environ.get("ROWS", 10_000_000)), 1024, 1024, 4096
+torch.cuda.set_device(0)
+t0 = time.time()
+table = PinnedFeatureTable(rows, dim, 0)
+fill_table(table.cpu_tensor, 0, device="cuda:0")
+indptr, indices = powerlaw_csc(rows, 12.0, seed=0, device="cuda:0")
+train_ids = torch.randperm(int(0.6 * rows), generator=torch.Generator().manual_seed(0))
+sampler = NeighborSampler([5, 5], seed=0)
+graph = sampler.make_graph(indptr, indices)
+batches = [sampler.sample(graph, train_ids[s * batch: (s + 1) * batch].cuda(), step=s)[0] for s in range(620)]
+torch.cuda.synchronize()
+print(f"# setup {time.time() - t0:.1f}s; rows per minibatch ~{sum(b.numel() for b in batches[400:]) / 220:.0f}", flush=True)
+ctrl = P.SSD_GNN_SSD_Controllers(1, 4096, 1024, 0, 0, dim, True)
+if "--stages" in sys.argv:
+    # where the fixed cost goes: K1's dependency chain cut after each link, launched right behind a real step's cold fill
+    import ctypes as C
+    from COALA_GNN_Pybind import _capi, current_stream
+    L = C.CDLL(os.environ["COALA_HIP_LIB"])
+    L.coala_dev_k1_stage.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+    cache = P.Isolated_Cache(ctrl := P.SSD_GNN_SSD_Controllers(1, 4096, 1024, 0, 0, dim, True), None, 0, 1, cache_mb, table.device_ptr, num_rows=rows,
+                             sync=False, max_batch=36864)
+    out = torch.empty((36864, dim), dtype=torch.float32, device="cuda")
+    for b in batches[:420]:
+        cache.read_feature(out.data_ptr(), b.data_ptr(), b.numel())
+    torch.cuda.synchronize()
+    names = {0: "empty kernel (launch + drain)", 1: "+ ids", 2: "+ tag sets, ballots", 3: "+ line loads of the hit rows (no stores)", 4: "product kernel without miss bookkeeping", 5: "product kernel (+ a memset of the verdict bytes)", 6: "product kernel without the set_cnt bump", 7: "product kernel, miss atomics only",
+             8: "product kernel, verdict stores only", -1: "empty event bracket"}
+    for stage in (-1, 0, 1, 2, 3, 4, 5, 4, 5):
+        evs = []
+        for k, b in enumerate(batches[420:619]):
+            cache.read_feature(out.data_ptr(), b.data_ptr(), b.numel())      # a real step: K1 + the PCIe-bound K2
+            nxt = batches[421 + k]
+            a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            if stage >= 0:
+                L.coala_dev_k1_stage(cache._h, out.data_ptr(), nxt.data_ptr(), nxt.numel(), stage, current_stream())
+            e.record()
+            evs.append((a, e))
+        torch.cuda.synchronize()
+        us = sorted(x.elapsed_time(y) * 1e3 for x, y in evs)
+        print(f"stage {stage:2d} {names[stage]:45s} mean {sum(us) / len(us):6.2f} us   median {us[len(us) // 2]:6.2f} us", flush=True)
+    sys.exit(0)
+variants = [a for a in sys.argv[1:] if not a.startswith("--")] or ["GRID=2048"]
+out = torch.empty((36864, dim), dtype=torch.float32, device="cuda")
+for rep in range(int(os.environ.get("REPS", 2))):
+    for v in variants:
+        for k in list(os.environ):
+            if k.startswith("COALA_K1_"):
+                del os.environ[k]
+        for kv in v.split(","):
+            if kv:
+                k, val = kv.split("=")
+                os.environ["COALA_K1_" + k] = val
+        cache = P.Isolated_Cache(ctrl, None, 0, 1, cache_mb, table.device_ptr, num_rows=rows, profile=True, sync=False, max_batch=36864)
+        for b in batches[:420]:
+            cache.read_feature(out.data_ptr(), b.data_ptr(), b.numel())
+        torch.cuda.synchronize()
+        cache.stats(reset=True)
+        cache.profile(reset=True)
+        pre = os.environ.get("COALA_K1_PRE", "")   # experiment: a wide kernel right in front of every K1 (clock / power-state probe)
+        scratch = torch.empty(int(pre) << 18, dtype=torch.float32, device="cuda") if pre else None
+        t1 = time.perf_counter()
+        for b in batches[420:]:
+            if scratch is not None:
+                scratch.zero_()
+            cache.read_feature(out.data_ptr(), b.data_ptr(), b.numel())
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t1) / 200 * 1e3
+        p = cache.profile()
+        hit, miss, _ = cache.stats()
+        alg = p.gather_rows * 264 + p.gather_hits * 2 * dim * 4
+        us = p.gather_ms / p.gather_launches * 1e3
+        print(f"{v:40s} K1 {us:7.2f} us (events, bracket {p.event_overhead_us:.2f} us)  {alg / p.gather_launches / us / 1e3:7.1f} GB/s = "
+              f"{alg / p.gather_launches / us / 1e3 / 80:5.1f} % of 8 TB/s   K2 {p.fill_ms / p.fill_launches * 1e3:8.1f} us   step {wall:.4f} ms   hit {hit / (hit + miss):.4f}", flush=True)
+        if os.environ.get("ALLHIT"):   # the BASELINE section 4 micro-benchmark on the same handle: 36,864 unique ids, every row a hit
+            ids = torch.randperm(rows, device="cuda", generator=torch.Generator(device="cuda").manual_seed(12345))[:36864]
+            for _ in range(3):
+                cache.read_feature(out.data_ptr(), ids.data_ptr(), ids.numel())
+            torch.cuda.synchronize()
+            cache.stats(reset=True)
+            cache.profile(reset=True)
+            for _ in range(100):
+                cache.read_feature(out.data_ptr(), ids.data_ptr(), ids.numel())
+            torch.cuda.synchronize()
+            p = cache.profile()
+            alg = p.gather_rows * 264 + p.gather_hits * 2 * dim * 4
+            us = p.gather_ms / p.gather_launches * 1e3
+            print(f"{'  all-hit 36,864 rows':40s} K1 {us:7.2f} us   {alg / p.gather_launches / us / 1e3:7.1f} GB/s = {alg / p.gather_launches / us / 1e3 / 80:5.1f} % of 8 TB/s", flush=True)
+        cache.close()

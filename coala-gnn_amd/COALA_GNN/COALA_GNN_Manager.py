@@ -274,6 +274,16 @@ class NativeExchange(object):
         self._lib.coala_comm_last_counts(self._h, send, recv)
         self.last_send_counts, self.last_recv_counts = list(send), list(recv)
 
+    def fetch_bucketed(self, ops, out_ptr, idx_ptr, n, counts_ptr):
+        """idx already bucketed by owner (NeighborSampler(bucket_by_owner=G)): no routing pass, rows received in place."""
+        from COALA_GNN_Pybind import current_stream
+        self._capi.check(self._lib.coala_cache_fetch_distributed_bucketed(ops._h, self._h, int(out_ptr) or None, int(idx_ptr) or None, int(n),
+                                                                           int(counts_ptr), current_stream()))
+        send = (self._C.c_int64 * self.world)()
+        recv = (self._C.c_int64 * self.world)()
+        self._lib.coala_comm_last_counts(self._h, send, recv)
+        self.last_send_counts, self.last_recv_counts = list(send), list(recv)
+
     # SSD_GNN_NVSHMEM_Cache.send_requests / read_feature keep the reference's two-call sequence: the second call does it all
     def send_requests(self, ops, idx_ptr, n, req_ptr, max_index):
         self._pending = (idx_ptr, n)
@@ -381,7 +391,17 @@ class COALA_GNN_Manager(object):
             ev_pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev_pair[0].record()
 
-        if self.cache_backend == "nvshmem":
+        # the sampler may have delivered the ids already bucketed by owner (NeighborSampler(bucket_by_owner=G)): the native exchange
+        # then skips its routing pass and receives the rows in place
+        owner_counts = None
+        if self.exchange is not None and hasattr(self.exchange, "fetch_bucketed") and len(batch) >= 3 and batch[2]:
+            oc = getattr(batch[2][0], "owner_counts", None)
+            if oc is not None and oc.numel() == self.MPI_comm_manager.local_size and batch[2][0].src_nodes is batch[0]:
+                owner_counts = oc
+        if owner_counts is not None:
+            return_torch = torch.empty([index_size, self.dim], dtype=torch.float, device=self.device)
+            self.exchange.fetch_bucketed(self.COALA_GNN_Cache, return_torch.data_ptr(), index_ptr, index_size, owner_counts.data_ptr())
+        elif self.cache_backend == "nvshmem":
             return_torch = self.NVshmem_tensor_manager.get_batch_tensor([index_size, self.dim])
             request_tensor_ptr = self.NVshmem_tensor_manager.get_index_tensor_ptr()
             self.COALA_GNN_Cache.send_requests(index_ptr, index_size, request_tensor_ptr, self.max_sample_size)

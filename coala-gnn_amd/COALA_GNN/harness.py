@@ -18,7 +18,7 @@ class SageMean(torch.nn.Module):
 
     def forward(self, blocks, h):
         for i, b in enumerate(blocks):
-            h = self.lin_self[i](h[: b.num_dst]) + self.lin_nbr[i](b.mean_aggregate(h))
+            h = self.lin_self[i](b.dst_rows(h)) + self.lin_nbr[i](b.mean_aggregate(h))
             if i + 1 < len(blocks):
                 h = torch.relu(h)
         return h

@@ -48,21 +48,36 @@ class Block(object):
     """One message-flow block in fixed-stride form: dst node d aggregates src rows nbr[d, j] >= 0.
     The first num_dst source nodes ARE the destination nodes (DGL's to_block convention)."""
 
-    def __init__(self, src_nodes, nbr, num_dst, graph=None):
+    def __init__(self, src_nodes, nbr, num_dst, graph=None, dst_in_src=None, dst_nodes=None, owner_counts=None, owner_counts_host=None):
         self.src_nodes = src_nodes          # int64 [num_src] global ids
         self.nbr = nbr                      # int32 [num_dst, fanout], -1 padded
         self.num_src = int(src_nodes.numel())
         self.num_dst = int(num_dst)
+        # Owner-bucketed input layer (NeighborSampler(bucket_by_owner=G)): src_nodes is bucket 0 | bucket 1 | ... (stable inside a
+        # bucket) instead of "dst nodes first", and dst_in_src[d] is where the d-th destination node sits in it.
+        self.dst_in_src = dst_in_src        # int32 [num_dst] or None
+        self.owner_counts = owner_counts    # device int64 [G] or None: what the partitioned fetch sends per owner
+        self.owner_counts_host = owner_counts_host
         self.srcdata = {"_ID": src_nodes}
-        self.dstdata = {"_ID": src_nodes[: self.num_dst]}
+        self.dstdata = {"_ID": src_nodes[: self.num_dst] if dst_nodes is None else dst_nodes}
         if graph is not None:
             for k, v in graph.ndata.items():  # blocks[-1].dstdata['labels'] (examples/sbatch_ssd_gnn_train.py:138)
                 self.dstdata[k] = v[self.dstdata["_ID"]] if v.device == src_nodes.device else v[self.dstdata["_ID"].cpu()]
+
+    def dst_rows(self, h_src):
+        """Rows of the destination nodes inside a per-source tensor: h_src[:num_dst] (DGL's convention), or a gather through
+        dst_in_src when the source list is owner-bucketed."""
+        if self.dst_in_src is None:
+            return h_src[: self.num_dst]
+        return h_src[self.dst_in_src.to(torch.int64)]
 
     def tensors(self):
         """Every device tensor this block holds (for cross-stream lifetime bookkeeping by the prefetching loader)."""
         yield self.src_nodes
         yield self.nbr
+        for t in (self.dst_in_src, self.owner_counts):
+            if t is not None:
+                yield t
         for d in (self.srcdata, self.dstdata):
             for v in d.values():
                 if isinstance(v, torch.Tensor):
@@ -91,12 +106,17 @@ class Block(object):
 class NeighborSampler(object):
     stream_safe = True  # every kernel and allocation of sample() goes to torch's current stream
 
-    def __init__(self, fanouts, seed=0):
+    def __init__(self, fanouts, seed=0, bucket_by_owner=0):
         self.fanouts = [int(f) for f in fanouts]
         if not 1 <= len(self.fanouts) <= 8:
             raise ValueError("1..8 layers")
         self.seed = int(seed)
         self.step = 0
+        # G > 0: deliver the input nodes bucketed by owner = id % G, the layout the owner-partitioned cache fetches without a
+        # routing pass and without an un-permute (blocks[0] then carries dst_in_src / owner_counts; see Block)
+        self.bucket_by_owner = int(bucket_by_owner)
+        if not 0 <= self.bucket_by_owner <= 64:
+            raise ValueError("bucket_by_owner must be 0..64")
 
     @staticmethod
     def make_graph(indptr, indices, ndata=None):
@@ -120,16 +140,34 @@ class NeighborSampler(object):
         fan = (C.c_int32 * L)(*rev)
         n_src = (C.c_int64 * L)()
         st = self.step if step is None else int(step)
+        G = self.bucket_by_owner
+        bk = None
+        if G > 0:
+            bucketed = torch.empty(max(caps[L], 1), dtype=torch.int64, device=g.device)
+            counts = torch.empty(G, dtype=torch.int64, device=g.device)
+            dst_in_src = torch.empty(max(caps[L - 1], 1), dtype=torch.int32, device=g.device)
+            bk = _capi.SamplerBucketing(G, 0, bucketed.data_ptr(), counts.data_ptr(), dst_in_src.data_ptr())
+        ticket = C.c_int64(-1)
+        # one kernel launch; the call returns when the per-layer counts have arrived in pinned host memory (event wait)
         _capi.check(_lib.coala_sampler_sample(g._h, seeds.data_ptr(), n, fan, L, self.seed, st, src_p, nbr_p, n_src,
-                                              current_stream()))
+                                              C.byref(bk) if bk is not None else None, C.byref(ticket), current_stream()))
+        counts_host = None
+        if G > 0:
+            ch = (C.c_int64 * G)()
+            _capi.check(_lib.coala_sampler_wait(g._h, ticket.value, None, ch))
+            counts_host = list(ch)
         if step is None:
             self.step += 1
         blocks = []
         n_dst = n
         for l in range(L):
             ns = int(n_src[l])
-            blocks.insert(0, Block(src[l][:ns], nbr[l][: n_dst * rev[l]].view(n_dst, rev[l]), n_dst,
-                                   graph=g if l == 0 else None))
+            nbr_l = nbr[l][: n_dst * rev[l]].view(n_dst, rev[l])
+            if G > 0 and l == L - 1:   # the input layer: owner-bucketed source list
+                blocks.insert(0, Block(bucketed[:ns], nbr_l, n_dst, graph=g if l == 0 else None, dst_in_src=dst_in_src[:n_dst],
+                                       dst_nodes=src[l][:n_dst], owner_counts=counts, owner_counts_host=counts_host))
+            else:
+                blocks.insert(0, Block(src[l][:ns], nbr_l, n_dst, graph=g if l == 0 else None))
             n_dst = ns
         input_nodes = blocks[0].src_nodes
         return input_nodes, seeds, blocks

@@ -36,6 +36,11 @@ class RowRedirect(C.Structure):
     _fields_ = [("begin", C.c_int64), ("end", C.c_int64), ("out", C.c_void_p), ("row_map", C.c_void_p)]
 
 
+class SamplerBucketing(C.Structure):
+    _fields_ = [("n_parts", C.c_int32), ("reserved", C.c_int32), ("bucketed_nodes", C.c_void_p), ("counts", C.c_void_p),
+                ("dst_in_src", C.c_void_p)]
+
+
 class CommProfile(C.Structure):
     _fields_ = [("rows_ms", C.c_double), ("calls", C.c_uint64), ("remote_rows_in", C.c_uint64)]
 
@@ -72,6 +77,7 @@ SYMBOLS = {
     "coala_comm_profile": (_I, [_VP, _I, C.POINTER(CommProfile), _I]),
     "coala_comm_last_counts": (_I, [_VP, _VP, _VP]),
     "coala_cache_fetch_distributed": (_I, [_VP, _VP, _VP, _VP, _I64, _VP]),
+    "coala_cache_fetch_distributed_bucketed": (_I, [_VP, _VP, _VP, _VP, _I64, _VP, _VP]),
     "coala_cache_color_counts": (_I, [_VP, _VP, C.c_int32, _VP]),
     "coala_cache_stats": (_I, [_VP, C.POINTER(_U64), C.POINTER(_U64), C.POINTER(_U64), _I, _VP]),
     "coala_cache_dump": (_I, [_VP, _VP, _VP, _VP, _VP]),
@@ -90,7 +96,8 @@ SYMBOLS = {
     "coala_sampler_create": (_I, [_I, _VP, _VP, _I64, _I64, C.POINTER(_VP)]),
     "coala_sampler_destroy": (_I, [_VP]),
     "coala_sampler_sample": (_I, [_VP, _VP, _I64, C.POINTER(C.c_int32), _I, _U64, _U64, C.POINTER(_VP), C.POINTER(_VP),
-                             C.POINTER(_I64), _VP]),
+                             C.POINTER(_I64), C.POINTER(SamplerBucketing), C.POINTER(_I64), _VP]),
+    "coala_sampler_wait": (_I, [_VP, _I64, C.POINTER(_I64), C.POINTER(_I64)]),
     "coala_shm_open": (_I, [C.c_char_p, _U64, _I, _I, C.POINTER(_VP)]),
     "coala_shm_host_ptr": (_VP, [_VP]),
     "coala_shm_device_ptr": (_VP, [_VP]),

@@ -416,8 +416,23 @@ int coala_comm_profile(coala_comm_t* c, int enable, coala_comm_profile_t* out, i
     return COALA_OK;
 }
 
+static int fetch_impl(coala_cache_t* h, coala_comm_t* c, float* out, const int64_t* idx, int64_t n, const int64_t* bucket_counts_dev, void* stream);
+
 int coala_cache_fetch_distributed(coala_cache_t* h, coala_comm_t* c, float* out, const int64_t* idx, int64_t n, void* stream) {
+    return fetch_impl(h, c, out, idx, n, nullptr, stream);
+}
+
+int coala_cache_fetch_distributed_bucketed(coala_cache_t* h, coala_comm_t* c, float* out, const int64_t* idx, int64_t n,
+                                           const int64_t* counts_dev, void* stream) {
+    if (!counts_dev) return fail(COALA_EINVAL, "null bucket counts");
+    return fetch_impl(h, c, out, idx, n, counts_dev, stream);
+}
+
+// bucket_counts_dev == nullptr: route here.  Otherwise idx is already bucketed by owner: node = idx, the map is the identity,
+// the rows of every peer are received straight into `out` and nothing is un-permuted.
+static int fetch_impl(coala_cache_t* h, coala_comm_t* c, float* out, const int64_t* idx, int64_t n, const int64_t* bucket_counts_dev, void* stream) {
     if (!h || !c) return fail(COALA_EINVAL, "null handle");
+    const bool bucketed = bucket_counts_dev != nullptr;
     if (c->broken) return fail(COALA_ECOMM, "this communicator failed in an earlier fetch and was aborted: destroy it");
     // every check that can fail locally comes BEFORE the first collective: a rank that returns between collectives strands its peers
     if (n < 0 || n > 0x7FFFFFFFll || (n > 0 && (!out || !idx))) return fail(COALA_EINVAL, "bad batch");
@@ -429,9 +444,11 @@ int coala_cache_fetch_distributed(coala_cache_t* h, coala_comm_t* c, float* out,
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipSetDevice(c->device));
     const uint64_t nb = (uint64_t)(n > 0 ? n : 1);
-    if ((rc = grow((void**)&c->node, &c->node_cap, nb, sizeof(int64_t), st))) return rc;
-    if ((rc = grow((void**)&c->map, &c->map_cap, nb, sizeof(int64_t), st))) return rc;
-    if ((rc = grow((void**)&c->rows_recv, &c->rows_recv_cap, nb * (uint64_t)dim, sizeof(float), st))) return rc;
+    if (!bucketed) {
+        if ((rc = grow((void**)&c->node, &c->node_cap, nb, sizeof(int64_t), st))) return rc;
+        if ((rc = grow((void**)&c->map, &c->map_cap, nb, sizeof(int64_t), st))) return rc;
+        if ((rc = grow((void**)&c->rows_recv, &c->rows_recv_cap, nb * (uint64_t)dim, sizeof(float), st))) return rc;
+    }
     // the usual step receives about as many ids as it sends: pre-size the owner-side buffers too, so that the grow after the
     // counts exchange (the one allocation that sits between collectives) only happens for skewed batches
     if ((rc = grow((void**)&c->recv_ids, &c->recv_cap, nb + (nb >> 2), sizeof(int64_t), st))) return rc;
@@ -439,8 +456,16 @@ int coala_cache_fetch_distributed(coala_cache_t* h, coala_comm_t* c, float* out,
     int64_t* send_cnt = c->counts_dev;
     int64_t* recv_cnt = c->counts_dev + G;
     int64_t* offsets = c->counts_dev + 2 * G; // [G+1]
-    // 1. bucket by owner (stable), packed layout
-    if ((rc = coala_cache_route(h, idx, n, G, 0, c->node, c->map, send_cnt, offsets, st))) return rc;
+    // 1. bucket by owner (stable), packed layout -- unless the sampler already delivered the ids that way
+    const int64_t* node = c->node;
+    float* rows_recv = c->rows_recv;
+    if (bucketed) {
+        HIPCHK(hipMemcpyAsync(send_cnt, bucket_counts_dev, (size_t)G * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
+        node = idx;
+        rows_recv = out; // bucket order IS the caller's order
+    } else if ((rc = coala_cache_route(h, idx, n, G, 0, c->node, c->map, send_cnt, offsets, st))) {
+        return rc;
+    }
 
     // from here on a local failure aborts the transport so that the peers error out instead of waiting for this rank
     auto broke = [&](int code) {
@@ -466,21 +491,21 @@ int coala_cache_fetch_distributed(coala_cache_t* h, coala_comm_t* c, float* out,
         c->last_send[p] = (int64_t)scnt[p];
         c->last_recv[p] = (int64_t)rcnt[p];
     }
-    if ((int64_t)acc != n) return broke(fail(COALA_ECOMM, "route produced %zu ids for a batch of %lld", acc, (long long)n));
+    if ((int64_t)acc != n) return broke(fail(COALA_ECOMM, "%s %zu ids for a batch of %lld", bucketed ? "the bucket counts sum to" : "route produced", acc, (long long)n));
     if (total_recv > 0x7FFFFFFFull) return broke(fail(COALA_ECOMM, "%zu ids routed to one owner in one step", total_recv));
     const uint64_t tr = total_recv ? total_recv : 1;
     if ((rc = grow((void**)&c->recv_ids, &c->recv_cap, tr, sizeof(int64_t), st))) return broke(rc);
     if ((rc = grow((void**)&c->rows_send, &c->rows_send_cap, tr * (uint64_t)dim, sizeof(float), st))) return broke(rc);
     // 4. ids to their owners (exact sizes); the own bucket is a device copy
-    if ((rc = c->tr->all_to_all_v(c->node, scnt.data(), sdis.data(), c->recv_ids, rcnt.data(), rdis.data(), sizeof(int64_t), true, st)))
+    if ((rc = c->tr->all_to_all_v(node, scnt.data(), sdis.data(), c->recv_ids, rcnt.data(), rdis.data(), sizeof(int64_t), true, st)))
         return broke(rc);
     // 5. owner side: ONE batch = the concatenation in source-rank order (DESIGN.md "Determinism contract").  Probe all of it;
     //    the own segment is delivered straight to out[map[..]] -- it never sees rows_send, the exchange or rows_recv.
     coala_row_redirect_t rd;
     rd.begin = (int64_t)rdis[me];
     rd.end = (int64_t)(rdis[me] + rcnt[me]);
-    rd.out = out;
-    rd.row_map = c->map + sdis[me];
+    rd.out = bucketed ? out + sdis[me] * (size_t)dim : out; // bucketed: the own bucket sits at its offset, in order
+    rd.row_map = bucketed ? nullptr : c->map + sdis[me];
     if ((rc = coala_cache_serve_probe_redirect(h, c->rows_send, c->recv_ids, (int64_t)total_recv, &rd, st))) return broke(rc);
     // 6. rounds: fill slice k of every peer's segment on the caller's stream, ship it on the comm stream while slice k+1 fills
     const int K = (G == 1) ? 1 : c->rounds;
@@ -528,7 +553,7 @@ int coala_cache_fetch_distributed(coala_cache_t* h, coala_comm_t* c, float* out,
             }
             if (hipStreamWaitEvent(c->cs, c->ev_fill[k], 0) != hipSuccess) return broke(fail(COALA_EHIP, "hipStreamWaitEvent failed"));
             if (k == 0 && t0) (void)hipEventRecord(t0, c->cs);
-            if ((rc = c->tr->all_to_all_v(c->rows_send, xs_cnt.data(), xs_dis.data(), c->rows_recv, xr_cnt.data(), xr_dis.data(), row_bytes, false, c->cs)))
+            if ((rc = c->tr->all_to_all_v(c->rows_send, xs_cnt.data(), xs_dis.data(), rows_recv, xr_cnt.data(), xr_dis.data(), row_bytes, false, c->cs)))
                 return broke(rc);
             if (hipEventRecord(c->ev_x[k], c->cs) != hipSuccess) return broke(fail(COALA_EHIP, "hipEventRecord failed"));
         }
@@ -541,7 +566,7 @@ int coala_cache_fetch_distributed(coala_cache_t* h, coala_comm_t* c, float* out,
         // 7. un-permute round by round as the rows arrive
         for (int k = 0; k < K; ++k) {
             if (hipStreamWaitEvent(st, c->ev_x[k], 0) != hipSuccess) return broke(fail(COALA_EHIP, "hipStreamWaitEvent failed"));
-            if ((rc = coala_cache_scatter_ranges(h, out, c->rows_recv, c->map, sb.data() + (size_t)k * G, se.data() + (size_t)k * G, G, st)))
+            if (!bucketed && (rc = coala_cache_scatter_ranges(h, out, c->rows_recv, c->map, sb.data() + (size_t)k * G, se.data() + (size_t)k * G, G, st)))
                 return broke(rc);
         }
     }

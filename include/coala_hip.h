@@ -187,6 +187,12 @@ int coala_comm_last_counts(const coala_comm_t* c, int64_t* send, int64_t* recv);
  * failure after it aborts the transport (ncclCommAbort) so that the peers fail too instead of waiting -- the communicator
  * then only accepts coala_comm_destroy. */
 int coala_cache_fetch_distributed(coala_cache_t* h, coala_comm_t* c, float* out, const int64_t* idx, int64_t n, void* stream);
+/* The same for ids that arrive ALREADY bucketed by owner (idx = bucket 0 | bucket 1 | ..., counts_dev = device int64[nranks]
+ * bucket sizes summing to n -- what coala_sampler_sample delivers with `bucketing`): no routing pass, no un-permute, the rows
+ * of owner p are received straight into out[offset of bucket p ...] and the own bucket is gathered in place.
+ * out[i] = row of idx[i] as above. */
+int coala_cache_fetch_distributed_bucketed(coala_cache_t* h, coala_comm_t* c, float* out, const int64_t* idx, int64_t n,
+                                           const int64_t* counts_dev, void* stream);
 /* Timing of the row exchange (all rounds of a fetch, HIP events on the communicator's stream; includes any wait for the fill of
  * a later round): enable = 1 / 0 switches it, -1 leaves it; out (nullable) receives the totals since the last reset. */
 typedef struct coala_comm_profile {
@@ -264,12 +270,29 @@ int coala_sampler_destroy(coala_sampler_t* s);
  * nodes.  Outputs, all device buffers owned by the caller, for cap_0 = n_seeds, cap_{l+1} = cap_l*(fanouts[l]+1):
  *   src_nodes_out[l] : int64[cap_{l+1}]        source (input) nodes of block l: its dst nodes first, then new ones
  *   nbr_local_out[l] : int32[cap_l*fanouts[l]] row d holds the local indices of dst d's sampled neighbours, -1 padded
- *   n_src_host[l]    : HOST int64, number of source nodes of block l (the call synchronises `stream` to deliver it;
- *                      pass NULL to stay asynchronous and read the counts yourself later)
- * Randomness: counter-based, keyed by (seed, step, layer, node id): same arguments, same sample. */
+ *   n_src_host[l]    : HOST int64, number of source nodes of block l.  Non-NULL: the call returns when the counts are there (it
+ *                      waits on an event behind the sampler's one kernel, not on the stream).  NULL: the call only enqueues;
+ *                      collect the counts later with coala_sampler_wait(ticket) -- up to 8 calls may be outstanding.
+ * The whole multi-layer sample is ONE kernel launch (a persistent kernel with grid barriers between its phases).
+ * Randomness: counter-based, keyed by (seed, step, layer, node id): same arguments, same sample.
+ *
+ * bucketing (nullable): additionally deliver the input nodes of the LAST layer bucketed by owner = id % n_parts, stable inside
+ * each bucket -- the layout the owner-partitioned fetch sends (coala_cache_fetch_distributed_bucketed: no routing pass, rows are
+ * received straight into the output tensor).  With it nbr_local_out[n_layers-1] indexes `bucketed_nodes` and dst_in_src[d] is
+ * the position of the block's d-th destination node in it (the "dst nodes first" convention cannot hold for a bucketed list);
+ * src_nodes_out[n_layers-1] still receives the unbucketed first-appearance list. */
+typedef struct coala_sampler_bucketing {
+    int32_t n_parts;         /* owners (1..64); 0 = off                                  */
+    int32_t reserved;
+    int64_t* bucketed_nodes; /* device int64[cap_L]                                      */
+    int64_t* counts;         /* device int64[n_parts]: bucket sizes                      */
+    int32_t* dst_in_src;     /* device int32[cap_{L-1}]                                  */
+} coala_sampler_bucketing_t;
 int coala_sampler_sample(coala_sampler_t* s, const int64_t* seeds, int64_t n_seeds, const int32_t* fanouts, int n_layers,
                          uint64_t seed, uint64_t step, int64_t* const* src_nodes_out, int32_t* const* nbr_local_out,
-                         int64_t* n_src_host, void* stream);
+                         int64_t* n_src_host, const coala_sampler_bucketing_t* bucketing, int64_t* ticket_out, void* stream);
+/* Counts of an earlier call (its ticket): n_src_host[n_layers] and, when it bucketed, bucket_counts_host[n_parts] (either NULL). */
+int coala_sampler_wait(coala_sampler_t* s, int64_t ticket, int64_t* n_src_host, int64_t* bucket_counts_host);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Shared pinned-host ("UVA") region.  Replaces SharedUVAManager (COALA_GNN_Modules/shared_UVA.cuh:26-115):

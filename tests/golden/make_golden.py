@@ -91,6 +91,10 @@ def main():
     ], "sampler": [
         sampler_case("sampler_55", 5000, 8.0, [5, 5], 256, 4),
         sampler_case("sampler_1055", 5000, 12.0, [10, 5, 5], 64, 5),
+        # the fan-outs of BASELINE.json configs[2], [4] and [3]
+        sampler_case("sampler_1010", 6000, 12.0, [10, 10], 128, 6),
+        sampler_case("sampler_101010", 6000, 12.0, [10, 10, 10], 48, 7),
+        sampler_case("sampler_15105", 6000, 14.5, [15, 10, 5], 64, 8),
     ], "feat_values": {f"{r},{c},{s}": float(O.feat_value(r, c, s)) for r, c, s in
                        [(0, 0, 0), (1, 0, 0), (0, 1, 0), (123456, 1023, 7), (99999999, 127, 1), (2**31, 5, 9)]}}
     with open(os.path.join(OUT, "golden.json"), "w") as f:

@@ -258,6 +258,77 @@ def test_native_fetch_inproc_ranks_match_oracle(hiplib, oracle, G, dim, cache_mb
         t.close()
 
 
+@pytest.mark.parametrize("G,dim,rounds", [(2, 256, 2), (4, 1024, 2), (8, 128, 3)])
+def test_native_bucketed_fetch_from_sampler_output(hiplib, oracle, G, dim, rounds):
+    """f-1 end to end: NeighborSampler(bucket_by_owner=G) -> coala_cache_fetch_distributed_bucketed on G in-process ranks (no routing
+    pass, rows received in place, own bucket gathered in place): delivered rows, owner counters and tag tables == orc_dist_fetch
+    fed with the same (bucketed) id lists."""
+    import ctypes as C
+    import threading
+    import torch
+    from COALA_GNN.COALA_GNN_Manager import NativeExchange
+    from COALA_GNN.sampler import NeighborSampler
+    from COALA_GNN.synthetic import powerlaw_csc
+    from COALA_GNN_Pybind import _capi
+    L = _capi.load()
+    num_rows, steps = 20000, 4
+    feat, tables, caches, orcs = _dist_fixture(hiplib, oracle, G, dim, 2, True, num_rows, seed=8, cls="Isolated_Cache")
+    indptr, indices = powerlaw_csc(num_rows, 10.0, seed=4, device="cuda")
+    group = C.c_void_p()
+    _capi.check(L.coala_comm_group_create(G, C.byref(group)))
+    exs = [NativeExchange(None, 0, r, G, 0, inproc_group=group, rounds=rounds) for r in range(G)]
+    samplers = [NeighborSampler([5, 5], seed=r, bucket_by_owner=G) for r in range(G)]
+    graphs = [s.make_graph(indptr, indices) for s in samplers]
+    got = [[None] * G for _ in range(steps)]
+    ids_seen = [[None] * G for _ in range(steps)]
+    errors = []
+    bar = threading.Barrier(G, timeout=180)
+
+    def worker(r):
+        try:
+            torch.cuda.set_device(0)
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                for step in range(steps):
+                    seeds = torch.randperm(num_rows, generator=torch.Generator().manual_seed(100 * step + r))[:64].cuda()
+                    input_nodes, _, blocks = samplers[r].sample(graphs[r], seeds)
+                    n = input_nodes.numel()
+                    out = torch.full((n, dim), -9.0, dtype=torch.float32, device="cuda")
+                    exs[r].fetch_bucketed(caches[r], out.data_ptr(), input_nodes.data_ptr(), n, blocks[0].owner_counts.data_ptr())
+                    stream.synchronize()
+                    got[step][r] = out.cpu().numpy()
+                    ids_seen[step][r] = input_nodes.cpu().numpy()
+                    assert exs[r].last_send_counts == blocks[0].owner_counts_host
+                    bar.wait()
+        except BaseException as e:  # noqa: BLE001
+            errors.append((r, repr(e)))
+            bar.abort()
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(G)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    for step in range(steps):
+        want = oracle.dist_fetch(orcs, ids_seen[step], oracle.SCHED_HITS_FIRST)
+        for r in range(G):
+            assert got[step][r].tobytes() == feat[ids_seen[step][r]].tobytes() == want[r].tobytes(), f"rank {r} step {step}"
+    for r in range(G):
+        assert caches[r].stats()[:2] == (orcs[r].hit_cnt, orcs[r].miss_cnt)
+        keys, cnt, _ = caches[r].dump()
+        assert np.array_equal(keys, orcs[r].keys()) and np.array_equal(cnt, orcs[r].set_cnt())
+    for e in exs:
+        e.close()
+    _capi.check(L.coala_comm_group_destroy(group))
+    for x in graphs:
+        x.close()
+    for c in caches:
+        c.close()
+    for t in set(tables):
+        t.close()
+
+
 def test_open_batch_is_guarded(hiplib, oracle):
     """a probe while a probed batch still waits for fills, a fill that overlaps an earlier one, or a fill for another
     batch size must be refused (stale verdicts would corrupt the next batch); serve_abort drops the open batch."""

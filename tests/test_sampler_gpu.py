@@ -108,3 +108,74 @@ def test_mean_aggregate_matches_dense(hiplib):
     want = np.stack([hc[r[r >= 0]].mean(0) if (r >= 0).any() else np.zeros(16, np.float32) for r in nbr])
     assert np.allclose(got.cpu().numpy(), want, rtol=1e-5, atol=1e-6)  # fp32 mean: 1e-5 relative
     g.close()
+
+
+@pytest.mark.parametrize("n_nodes,avg_deg,fanouts,n_seeds,G", [(50000, 12.0, [5, 5], 1024, 8), (30000, 12.0, [10, 10], 300, 3),
+                                                              (20000, 8.0, [4], 500, 2), (30000, 25.0, [15, 10, 5], 100, 4)])
+def test_sampler_owner_bucketing(hiplib, n_nodes, avg_deg, fanouts, n_seeds, G):
+    """bucket_by_owner=G: the input nodes come out as a STABLE partition of the unbucketed list by id % G, with the bucket sizes,
+    and the input block re-indexed so that it addresses exactly the same nodes -- f-1: the layout the partitioned fetch sends."""
+    import torch
+    from COALA_GNN.sampler import NeighborSampler
+    indptr, indices = _graph(torch, n_nodes, avg_deg, seed=5)
+    plain = NeighborSampler(fanouts, seed=3)
+    buck = NeighborSampler(fanouts, seed=3, bucket_by_owner=G)
+    g = plain.make_graph(indptr, indices, ndata={"labels": torch.arange(n_nodes, device="cuda") % 19})
+    gen = torch.Generator().manual_seed(2)
+    for step in range(3):
+        seeds = torch.randperm(n_nodes, generator=gen)[:n_seeds].cuda()
+        in_p, _, bl_p = plain.sample(g, seeds)
+        in_b, _, bl_b = buck.sample(g, seeds)
+        a, b = bl_p[0], bl_b[0]
+        ids = in_p.cpu().numpy()
+        want = np.concatenate([ids[ids % G == o] for o in range(G)])            # stable partition
+        assert np.array_equal(in_b.cpu().numpy(), want)
+        assert b.owner_counts.cpu().tolist() == b.owner_counts_host == [int((ids % G == o).sum()) for o in range(G)]
+        assert b.num_src == a.num_src and b.num_dst == a.num_dst
+        # same neighbours through the new indices; -1 padding untouched
+        na, nb = a.nbr.cpu().numpy(), b.nbr.cpu().numpy()
+        assert np.array_equal(na < 0, nb < 0)
+        assert np.array_equal(ids[na[na >= 0]], want[nb[nb >= 0]])
+        # destination nodes: found through dst_in_src
+        dst_nodes = ids[: a.num_dst]
+        assert np.array_equal(want[b.dst_in_src.cpu().numpy()], dst_nodes)
+        assert torch.equal(b.dstdata["_ID"], a.dstdata["_ID"])
+        h = torch.rand(b.num_src, 8, device="cuda")
+        assert torch.equal(b.dst_rows(h), h[b.dst_in_src.long()])
+        for x, y in zip(bl_p[1:], bl_b[1:]):                                     # the other layers are untouched
+            assert torch.equal(x.src_nodes, y.src_nodes) and torch.equal(x.nbr, y.nbr) and y.dst_in_src is None
+        if len(fanouts) == 1:
+            assert torch.equal(bl_b[-1].dstdata["labels"], seeds % 19)
+    g.close()
+
+
+def test_sampler_async_tickets(hiplib):
+    """n_src_host = NULL: the call only enqueues its one kernel; the counts of up to 8 outstanding calls are collected later."""
+    import ctypes as C
+    import torch
+    from COALA_GNN.sampler import NeighborSampler
+    from COALA_GNN_Pybind import _capi, current_stream
+    L = _capi.load()
+    indptr, indices = _graph(torch, 20000, 10.0, seed=1)
+    smp = NeighborSampler([5, 5], seed=1)
+    g = smp.make_graph(indptr, indices)
+    ref = [smp.sample(g, torch.arange(k * 100, k * 100 + 64, device="cuda"), step=k) for k in range(5)]
+    tickets, outs = [], []
+    for k in range(5):
+        seeds = torch.arange(k * 100, k * 100 + 64, device="cuda")
+        src = [torch.empty(64 * 6, dtype=torch.int64, device="cuda"), torch.empty(64 * 36, dtype=torch.int64, device="cuda")]
+        nbr = [torch.empty(64 * 5, dtype=torch.int32, device="cuda"), torch.empty(64 * 6 * 5, dtype=torch.int32, device="cuda")]
+        t = C.c_int64(-1)
+        _capi.check(L.coala_sampler_sample(g._h, seeds.data_ptr(), 64, (C.c_int32 * 2)(5, 5), 2, 1, k, (C.c_void_p * 2)(*[x.data_ptr() for x in src]),
+                                           (C.c_void_p * 2)(*[x.data_ptr() for x in nbr]), None, None, C.byref(t), current_stream()))
+        tickets.append(t.value)
+        outs.append((seeds, src, nbr))
+    for k in reversed(range(5)):                                                  # any order
+        n_src = (C.c_int64 * 2)()
+        _capi.check(L.coala_sampler_wait(g._h, tickets[k], n_src, None))
+        blocks = ref[k][2]
+        assert [n_src[0], n_src[1]] == [blocks[1].num_src, blocks[0].num_src]
+        assert torch.equal(outs[k][1][1][: n_src[1]], blocks[0].src_nodes)
+    with pytest.raises(RuntimeError, match="ticket"):
+        _capi.check(L.coala_sampler_wait(g._h, 99, None, None))
+    g.close()

@@ -14,11 +14,17 @@
 //     whatever order the hash-table inserts land in;
 //   * nbr_local[d*f + j] = index of the j-th sampled neighbour of dst d inside the source list, or -1.
 //
-// ONE launch per call: a persistent kernel of at most one 256-thread block per CU walks through every phase of every layer
-// (clear table -> sample + insert -> count first occurrences -> assign -> relabel, then the optional owner bucketing of the
-// input nodes) with grid-wide barriers in between, layer l+1 reading its destination count from what layer l just produced.
-// Round 1 issued 10 launches per 2-layer call (and a blocking read of the counts); the kernel boundaries, not the work, were
-// the cost.  The counts are stored straight into pinned host memory by the kernel; the host waits for them on an event.
+// Three launches per layer, nothing else on the stream (round 1: five launches + a memset per layer, a D2H copy and a stream
+// synchronisation per call):
+//   sample_insert   draw + hash insert;
+//   scan_assign     first-occurrence flags -> positions in ONE pass: tiles are handed out by an atomic ticket and chained with a
+//                   decoupled look-back over generation-tagged status words (no clearing pass, no second kernel for the tile sums);
+//   relabel_clear   neighbour -> local index, and the hash table of the NEXT layer (or of the next call) is cleared alongside.
+// Layer l+1 reads its destination count from device memory; the counts also go straight into pinned host memory from the kernel
+// that produces them, and the host collects them by waiting on an event behind the last kernel -- never on the stream.
+// (Tried and dropped: the whole call as one persistent kernel with grid barriers.  Every barrier needs a device-scope fence, i.e.
+// an L2 write-back + invalidate issued by every block; 9 barriers cost more than the 10 kernel boundaries they replaced: 0.186 ms
+// against 0.107 ms per 5,5 call.)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -40,7 +46,7 @@ constexpr int kBlock = 256;                 // threads per block
 constexpr int kWavesPerBlock = kBlock / 64;
 constexpr int kItems = 4;                   // items per thread in the scan phases
 constexpr int kTile = kBlock * kItems;      // items per block tile
-constexpr int kMaxTiles = 4096;             // tiles per layer the in-LDS scan of the tile sums can hold (4.19 M items)
+constexpr int kMaxTiles = 8192;             // tiles per layer (8.4 M items): status words of the single-pass scan
 constexpr int kRing = 8;                    // calls whose counts may be outstanding at once
 constexpr int kMaxParts = 64;
 constexpr int kRouteTile = 64 * kItems;     // ids per wave step of the bucketing phases
@@ -70,66 +76,22 @@ __host__ __device__ inline uint32_t table_size(int64_t n_items) { // power of tw
     return t;
 }
 
-struct SampleArgs {
+struct Graph {
     const int64_t* indptr;
     const int64_t* indices;
     int64_t num_nodes;
-    const int64_t* seeds;
-    int64_t n_seeds;
-    int32_t n_layers;
-    int32_t fanout[COALA_SAMPLER_MAX_LAYERS];
-    int64_t* src_out[COALA_SAMPLER_MAX_LAYERS];
-    int32_t* nbr_local_out[COALA_SAMPLER_MAX_LAYERS];
-    uint64_t seed, step;
-    // workspace
-    int64_t* nbr;             // [max cap_l * f_l] sampled neighbours of the current layer (global ids, -1 padded)
+};
+
+struct Table {
     long long* keys;          // [table] hash keys
     uint32_t* minpos;         // [table] first position of the key in the (dst..., neighbours...) item list
     uint32_t* local_of_slot;  // [table] index of the key in the source list
-    uint32_t* slot_of_item;   // [max items]
-    uint32_t* tile_sums;      // [max(kMaxTiles, wave tiles * n_parts)]
-    int64_t* counts_host;     // device alias of pinned host memory: [n_layers] source counts, then [n_parts] bucket sizes
-    unsigned long long* barrier;  // monotonic arrival counter of the grid barrier
-    unsigned long long barrier_base;
-    int* error;               // device alias of a pinned host flag: 1 = a grid barrier timed out
-    // optional: the input nodes of the LAST layer bucketed by owner = id % n_parts (stable), blocks re-indexed accordingly
-    int32_t n_parts;
-    int32_t pshift;           // log2(n_parts) or -1
-    int64_t* bucketed;        // [cap_L]
-    int64_t* bucket_counts;   // device [n_parts]
-    int32_t* dst_in_src;      // [cap_{L-1}] position of dst d of the last block inside `bucketed`
-    uint32_t* new_of_old;     // [cap_L] workspace
 };
 
-// Grid-wide barrier of a kernel whose blocks are all resident (grid <= one block per CU).  Bounded: if a block of the grid never
-// arrives (it faulted), the others give up after ~2 s, raise the error flag and leave -- the grid always drains.
-__device__ __forceinline__ bool grid_sync(const SampleArgs& a, unsigned long long& target, int* s_ok) {
-    __syncthreads();
-    target += gridDim.x;
-    if (threadIdx.x == 0) {
-        __threadfence(); // this block's writes are visible device-wide before it reports in
-        atomicAdd(a.barrier, 1ull);
-        int ok = 1;
-        long spins = 0;
-        while (__hip_atomic_load(a.barrier, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(2);
-            if ((++spins & 0xFFF) == 0 && (spins > (1L << 22) || __hip_atomic_load(a.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM))) {
-                __hip_atomic_store(a.error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                ok = 0;
-                break;
-            }
-        }
-        __threadfence();
-        *s_ok = ok;
-    }
-    __syncthreads();
-    return *s_ok != 0;
-}
-
-__device__ __forceinline__ void clear_table(const SampleArgs& a, uint32_t tbl) {
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < tbl; i += gridDim.x * kBlock) {
-        a.keys[i] = kEmpty;
-        a.minpos[i] = 0xFFFFFFFFu;
+__device__ __forceinline__ void clear_table(const Table& t, uint32_t tbl) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < tbl; i += gridDim.x * blockDim.x) {
+        t.keys[i] = kEmpty;
+        t.minpos[i] = 0xFFFFFFFFu;
     }
 }
 
@@ -138,9 +100,12 @@ __device__ __forceinline__ void clear_table(const SampleArgs& a, uint32_t tbl) {
 // step (bit-identical to the sequential loop of the CPU twin), then every lane loads ITS neighbour and inserts it into the
 // hash table; lane `fanout` inserts the destination node itself.
 template <int GS>
-__device__ __forceinline__ void phase_sample_insert(const SampleArgs& a, const int64_t* __restrict__ dst, int64_t n_dst, int fanout, int layer,
-                                                    uint32_t mask) {
+__global__ __launch_bounds__(kBlock) void sample_insert_kernel(Graph g, const int64_t* __restrict__ dst, const int64_t* __restrict__ n_dst_dev,
+                                                               int64_t n_dst_value /* used when n_dst_dev is null: the first layer */, int fanout, uint64_t seed, uint64_t step, int layer, int64_t* __restrict__ nbr,
+                                                               Table tb, uint32_t* __restrict__ slot_of_item) {
     constexpr int GPW = 64 / GS; // groups per wave
+    const int64_t n_dst = n_dst_dev ? *n_dst_dev : n_dst_value;
+    const uint32_t mask = table_size(n_dst * (fanout + 1)) - 1;
     const int lane = threadIdx.x & 63;
     const int gl = lane % GS;
     const int gbase = lane - gl;
@@ -151,11 +116,11 @@ __device__ __forceinline__ void phase_sample_insert(const SampleArgs& a, const i
         const int64_t d = d0 + lane / GS;
         const bool active = d < n_dst;
         const int64_t v = active ? dst[d] : -1;
-        const bool okv = active && v >= 0 && v < a.num_nodes;
-        const int64_t start = okv ? a.indptr[v] : 0;
-        const int64_t deg = okv ? a.indptr[v + 1] - start : 0;
+        const bool okv = active && v >= 0 && v < g.num_nodes;
+        const int64_t start = okv ? g.indptr[v] : 0;
+        const int64_t deg = okv ? g.indptr[v + 1] - start : 0;
         // candidate of lane c = gl (Floyd step j = deg - fanout + c)
-        const uint64_t key = sample_key(a.seed, a.step, layer, (uint64_t)v);
+        const uint64_t key = sample_key(seed, step, layer, (uint64_t)v);
         const int64_t jmine = deg - fanout + gl;
         const int64_t t = (deg > fanout && gl < fanout) ? (int64_t)__umul64hi(splitmix64(key + (uint64_t)gl), (uint64_t)(jmine + 1)) : -1;
         int64_t chosen = -2;
@@ -166,8 +131,8 @@ __device__ __forceinline__ void phase_sample_insert(const SampleArgs& a, const i
         }
         int64_t pick = -1;
         if (gl < fanout) pick = (deg <= fanout) ? (gl < deg ? (int64_t)gl : -1) : chosen;
-        const int64_t nb = (okv && pick >= 0) ? a.indices[start + pick] : kEmpty;
-        if (active && gl < fanout) a.nbr[d * fanout + gl] = nb;
+        const int64_t nb = (okv && pick >= 0) ? g.indices[start + pick] : kEmpty;
+        if (active && gl < fanout) nbr[d * fanout + gl] = nb;
         // ---- hash insert: neighbours at positions n_dst + d*fanout + gl, the node itself at position d
         int64_t k = kEmpty;
         int64_t p = -1;
@@ -175,247 +140,253 @@ __device__ __forceinline__ void phase_sample_insert(const SampleArgs& a, const i
         else if (active && gl == fanout) { k = v; p = d; }
         if (p >= 0) {
             if (k < 0) {
-                a.slot_of_item[p] = 0xFFFFFFFFu;
+                slot_of_item[p] = 0xFFFFFFFFu;
             } else {
                 uint32_t s = hash_slot(k, mask);
                 while (true) {
-                    const long long cur = a.keys[s];
+                    const long long cur = tb.keys[s];
                     if (cur == k) break;
                     if (cur == kEmpty) {
-                        const long long old = atomicCAS((unsigned long long*)(a.keys + s), (unsigned long long)kEmpty, (unsigned long long)k);
+                        const long long old = atomicCAS((unsigned long long*)(tb.keys + s), (unsigned long long)kEmpty, (unsigned long long)k);
                         if (old == kEmpty || old == k) break;
                     }
                     s = (s + 1) & mask;
                 }
-                atomicMin(a.minpos + s, (uint32_t)p);
-                a.slot_of_item[p] = s;
+                atomicMin(tb.minpos + s, (uint32_t)p);
+                slot_of_item[p] = s;
             }
         }
     }
 }
 
-__device__ __forceinline__ uint32_t first_flag(const SampleArgs& a, int64_t p, int64_t n_items) {
+__device__ __forceinline__ uint32_t first_flag(const uint32_t* __restrict__ slot_of_item, const uint32_t* __restrict__ minpos, int64_t p,
+                                               int64_t n_items) {
     if (p >= n_items) return 0;
-    const uint32_t s = a.slot_of_item[p];
-    return (s != 0xFFFFFFFFu && a.minpos[s] == (uint32_t)p) ? 1u : 0u;
+    const uint32_t s = slot_of_item[p];
+    return (s != 0xFFFFFFFFu && minpos[s] == (uint32_t)p) ? 1u : 0u;
 }
 
-// exclusive scan of s_vals[0..n) in place (n <= kMaxTiles), every thread of the block; returns the total
-__device__ __forceinline__ uint32_t block_scan_inplace(uint32_t* s_vals, int n, uint32_t* s_part) {
-    const int per = (n + kBlock - 1) / kBlock;
-    const int lo = threadIdx.x * per, hi = min(lo + per, n);
-    uint32_t sum = 0;
-    for (int i = lo; i < hi; ++i) sum += s_vals[i];
-    s_part[threadIdx.x] = sum;
+// Single-pass scan: a block takes the next tile with an atomic ticket (so every predecessor of its tile has already started),
+// publishes the tile's count as an AGGREGATE, looks back over its predecessors until it meets an INCLUSIVE prefix, publishes its
+// own INCLUSIVE prefix and numbers its first occurrences.  Status words carry the launch's generation: nothing to reset.
+//   word = gen << 34 | status << 32 | value          status: 1 = aggregate, 2 = inclusive prefix
+constexpr unsigned long long kAggregate = 1ull << 32, kInclusive = 2ull << 32;
+__global__ __launch_bounds__(kBlock) void scan_assign_kernel(const int64_t* __restrict__ dst, const int64_t* __restrict__ nbr,
+                                                             const int64_t* __restrict__ n_dst_dev, int64_t n_dst_value, int fanout,
+                                                             const uint32_t* __restrict__ slot_of_item, Table tb, unsigned long long* __restrict__ status,
+                                                             unsigned long long* __restrict__ ticket, unsigned long long ticket_base,
+                                                             unsigned long long gen, int64_t* __restrict__ src_nodes, int64_t* __restrict__ n_src_dev,
+                                                             int64_t* __restrict__ n_src_host) {
+    __shared__ uint32_t s_woff[kWavesPerBlock];
+    __shared__ unsigned long long s_tile;
+    __shared__ uint32_t s_prefix;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t n_dst = n_dst_dev ? *n_dst_dev : n_dst_value;
+    const int64_t n_items = n_dst * (fanout + 1);
+    const int64_t n_tiles = (n_items + kTile - 1) / kTile;
+    if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1ull) - ticket_base;
     __syncthreads();
-    for (int off = 1; off < kBlock; off <<= 1) {
-        const uint32_t v = (threadIdx.x >= (unsigned)off) ? s_part[threadIdx.x - off] : 0;
-        __syncthreads();
-        s_part[threadIdx.x] += v;
-        __syncthreads();
+    const int64_t tile = (int64_t)s_tile;
+    if (tile >= n_tiles) { // launched for the capacity; the block that would own the first unused tile reports an empty layer
+        if (tile == 0 && threadIdx.x == 0) { *n_src_dev = 0; *n_src_host = 0; }
+        return;
     }
-    uint32_t run = s_part[threadIdx.x] - sum;
-    for (int i = lo; i < hi; ++i) {
-        const uint32_t c = s_vals[i];
-        s_vals[i] = run;
-        run += c;
+    const int64_t base = tile * kTile + (int64_t)threadIdx.x * kItems;
+    uint32_t fl[kItems];
+    uint32_t c = 0;
+    for (int i = 0; i < kItems; ++i) { fl[i] = first_flag(slot_of_item, tb.minpos, base + i, n_items); c += fl[i]; }
+    uint32_t incl = c; // inclusive scan inside the wave
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(incl, off);
+        if (lane >= off) incl += v;
     }
-    const uint32_t total = s_part[kBlock - 1];
+    if (lane == 63) s_woff[w] = incl;
     __syncthreads();
-    return total;
+    uint32_t wbase = 0, total = 0;
+    for (int q = 0; q < kWavesPerBlock; ++q) {
+        if (q < w) wbase += s_woff[q];
+        total += s_woff[q];
+    }
+    if (threadIdx.x == 0) {
+        const unsigned long long tag = gen << 34;
+        uint32_t prefix = 0;
+        if (tile > 0) {
+            __hip_atomic_store(status + tile, tag | kAggregate | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int64_t t = tile - 1; t >= 0;) { // decoupled look-back
+                const unsigned long long v = __hip_atomic_load(status + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((v >> 34) != gen || !(v & (kAggregate | kInclusive))) { __builtin_amdgcn_s_sleep(1); continue; } // not published yet
+                prefix += (uint32_t)v;
+                if (v & kInclusive) break;
+                --t;
+            }
+        }
+        __hip_atomic_store(status + tile, tag | kInclusive | (prefix + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_prefix = prefix;
+        if (tile == n_tiles - 1) { // layer l+1 (and the host) read the number of source nodes from here
+            *n_src_dev = (int64_t)(prefix + total);
+            *n_src_host = (int64_t)(prefix + total);
+        }
+    }
+    __syncthreads();
+    uint32_t run = s_prefix + wbase + incl - c;
+    for (int i = 0; i < kItems; ++i) {
+        if (fl[i]) {
+            const int64_t p = base + i;
+            src_nodes[run] = item_key(dst, nbr, n_dst, p);
+            tb.local_of_slot[slot_of_item[p]] = run;
+            ++run;
+        }
+    }
 }
 
+// neighbour -> local index in the source list; alongside, the hash table for what comes next is cleared (keys / minpos are no
+// longer read by this layer): next_items_dev != null -> the next layer's size is read from the device, else next_items (next call)
+__global__ __launch_bounds__(kBlock) void relabel_clear_kernel(const int64_t* __restrict__ n_dst_dev, int64_t n_dst_value, int fanout, const uint32_t* __restrict__ slot_of_item,
+                                                               Table tb, int32_t* __restrict__ nbr_local, const int64_t* __restrict__ next_n_dst_dev,
+                                                               int next_fanout, int64_t next_items) {
+    const int64_t n_dst = n_dst_dev ? *n_dst_dev : n_dst_value;
+    const int64_t n_nbr = n_dst * fanout;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n_nbr; q += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t s = slot_of_item[n_dst + q];
+        nbr_local[q] = (s == 0xFFFFFFFFu) ? -1 : (int32_t)tb.local_of_slot[s];
+    }
+    clear_table(tb, table_size(next_n_dst_dev ? *next_n_dst_dev * (next_fanout + 1) : next_items));
+}
+
+// ---------------------------------------------------------------------------------------------------------- owner bucketing
+// Stable partition of the input nodes by owner = id % n_parts (same ballot / prefix-sum scheme as the cache's route kernels), then
+// the last block is re-indexed through the permutation.
 __device__ __forceinline__ uint32_t owner_of(uint64_t id, uint32_t n_parts, int pshift) {
     if (pshift >= 0) return (uint32_t)id & (n_parts - 1);
     if ((id >> 32) == 0) return (uint32_t)id % n_parts;
     return (uint32_t)(id % n_parts);
 }
 
-__global__ __launch_bounds__(kBlock) void sample_layers_kernel(SampleArgs a) {
-    __shared__ uint32_t s_tiles[kMaxTiles];
-    __shared__ uint32_t s_part[kBlock];
-    __shared__ uint32_t s_woff[kWavesPerBlock];
-    __shared__ int s_ok;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    unsigned long long target = a.barrier_base;
-    const int64_t* dst = a.seeds;
-    int64_t n_dst = a.n_seeds;
-    clear_table(a, table_size(n_dst * (a.fanout[0] + 1)));
-    if (!grid_sync(a, target, &s_ok)) return;
-    for (int l = 0; l < a.n_layers; ++l) {
-        const int f = a.fanout[l];
-        const int64_t n_items = n_dst * (f + 1);
-        const uint32_t mask = table_size(n_items) - 1;
-        // ---- sample + insert
-        if (f < 16) phase_sample_insert<16>(a, dst, n_dst, f, l, mask);
-        else if (f < 32) phase_sample_insert<32>(a, dst, n_dst, f, l, mask);
-        else phase_sample_insert<64>(a, dst, n_dst, f, l, mask);
-        if (!grid_sync(a, target, &s_ok)) return;
-        // ---- count first occurrences per tile
-        const int n_tiles = (int)((n_items + kTile - 1) / kTile);
-        for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-            const int64_t base = (int64_t)tile * kTile + (int64_t)threadIdx.x * kItems;
-            uint32_t c = 0;
-            for (int i = 0; i < kItems; ++i) c += first_flag(a, base + i, n_items);
-            for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
-            if (lane == 0) s_woff[w] = c;
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                uint32_t t = 0;
-                for (int q = 0; q < kWavesPerBlock; ++q) t += s_woff[q];
-                a.tile_sums[tile] = t;
+__global__ __launch_bounds__(kBlock) void bucket_count_kernel(const int64_t* __restrict__ src, const int64_t* __restrict__ n_src_dev, uint32_t P,
+                                                              int pshift, uint32_t* __restrict__ wave_counts) {
+    const int lane = threadIdx.x & 63;
+    const int64_t n_src = *n_src_dev;
+    const int64_t n_wt = (n_src + kRouteTile - 1) / kRouteTile;
+    const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * kWavesPerBlock;
+    for (int64_t wt = wave; wt < n_wt; wt += n_waves) {
+        uint32_t mine = 0; // lane g accumulates the count of owner g
+        for (int j = 0; j < kItems; ++j) {
+            const int64_t i = wt * kRouteTile + j * 64 + lane;
+            const uint32_t o = (i < n_src) ? owner_of((uint64_t)src[i], P, pshift) : 0xFFFFFFFFu;
+            for (uint32_t g = 0; g < P; ++g) {
+                const uint64_t m = __ballot(o == g);
+                if ((uint32_t)lane == g) mine += (uint32_t)__builtin_popcountll(m);
             }
-            __syncthreads();
         }
-        if (!grid_sync(a, target, &s_ok)) return;
-        // ---- assign: every block scans the tile sums in LDS, then numbers the first occurrences of its own tiles
-        for (int i = threadIdx.x; i < n_tiles; i += kBlock) s_tiles[i] = a.tile_sums[i];
-        __syncthreads();
-        const int64_t n_src = (int64_t)block_scan_inplace(s_tiles, n_tiles, s_part);
-        int64_t* __restrict__ src = a.src_out[l];
-        for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-            const int64_t base = (int64_t)tile * kTile + (int64_t)threadIdx.x * kItems;
-            uint32_t fl[kItems];
-            uint32_t c = 0;
-            for (int i = 0; i < kItems; ++i) { fl[i] = first_flag(a, base + i, n_items); c += fl[i]; }
-            uint32_t incl = c; // inclusive scan inside the wave
+        if ((uint32_t)lane < P) wave_counts[wt * P + lane] = mine;
+    }
+}
+
+// one block, one wave per owner column: exclusive scan over the wave tiles with a running carry, bucket sizes and bases
+__global__ __launch_bounds__(1024) void bucket_scan_kernel(uint32_t* __restrict__ wave_counts, const int64_t* __restrict__ n_src_dev, uint32_t P,
+                                                           int64_t* __restrict__ counts_out, int64_t* __restrict__ counts_host, int64_t* __restrict__ bases) {
+    __shared__ int64_t totals[kMaxParts];
+    const int lane = threadIdx.x & 63;
+    const int64_t n_wt = (*n_src_dev + kRouteTile - 1) / kRouteTile;
+    for (uint32_t g = threadIdx.x >> 6; g < P; g += blockDim.x >> 6) {
+        uint32_t carry = 0;
+        for (int64_t t0 = 0; t0 < n_wt; t0 += 64) {
+            const int64_t t = t0 + lane;
+            const uint32_t c = (t < n_wt) ? wave_counts[t * P + g] : 0u;
+            uint32_t incl = c;
             for (int off = 1; off < 64; off <<= 1) {
                 const uint32_t v = __shfl_up(incl, off);
                 if (lane >= off) incl += v;
             }
-            if (lane == 63) s_woff[w] = incl;
-            __syncthreads();
-            uint32_t wbase = 0;
-            for (int q = 0; q < w; ++q) wbase += s_woff[q];
-            uint32_t run = s_tiles[tile] + wbase + incl - c;
-            for (int i = 0; i < kItems; ++i) {
-                if (fl[i]) {
-                    const int64_t p = base + i;
-                    src[run] = item_key(dst, a.nbr, n_dst, p);
-                    a.local_of_slot[a.slot_of_item[p]] = run;
-                    ++run;
-                }
-            }
-            __syncthreads();
+            if (t < n_wt) wave_counts[t * P + g] = carry + incl - c;
+            carry += __shfl(incl, 63);
         }
-        if (blockIdx.x == 0 && threadIdx.x == 0) a.counts_host[l] = n_src;
-        if (!grid_sync(a, target, &s_ok)) return;
-        // ---- relabel: neighbour -> index in the source list; the table of the next layer is cleared alongside (keys / minpos are
-        //      no longer read in this layer)
-        {
-            const int64_t n_nbr = n_dst * f;
-            int32_t* __restrict__ loc = a.nbr_local_out[l];
-            for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q < n_nbr; q += (int64_t)gridDim.x * kBlock) {
-                const uint32_t s = a.slot_of_item[n_dst + q];
-                loc[q] = (s == 0xFFFFFFFFu) ? -1 : (int32_t)a.local_of_slot[s];
-            }
-            if (l + 1 < a.n_layers) clear_table(a, table_size(n_src * (a.fanout[l + 1] + 1)));
-        }
-        const bool last = l + 1 == a.n_layers;
-        if (last && a.n_parts <= 0) return; // nothing after the last relabel reads what other blocks wrote
-        if (!grid_sync(a, target, &s_ok)) return;
-        if (last) {
-            // ---- owner bucketing of the input nodes (stable inside each bucket): per wave tile of 256 ids, per-owner counts by
-            //      ballots -> per-owner scan over the wave tiles -> scatter -> re-index the last block
-            const uint32_t P = (uint32_t)a.n_parts;
-            const int64_t n_wt = (n_src + kRouteTile - 1) / kRouteTile;
-            const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + w;
-            const int64_t n_waves = (int64_t)gridDim.x * kWavesPerBlock;
-            for (int64_t wt = wave; wt < n_wt; wt += n_waves) {
-                uint32_t mine = 0; // lane g accumulates the count of owner g
-                for (int j = 0; j < kItems; ++j) {
-                    const int64_t i = wt * kRouteTile + j * 64 + lane;
-                    const uint32_t o = (i < n_src) ? owner_of((uint64_t)src[i], P, a.pshift) : 0xFFFFFFFFu;
-                    for (uint32_t g = 0; g < P; ++g) {
-                        const uint64_t m = __ballot(o == g);
-                        if ((uint32_t)lane == g) mine += (uint32_t)__builtin_popcountll(m);
-                    }
-                }
-                if ((uint32_t)lane < P) a.tile_sums[wt * P + lane] = mine;
-            }
-            if (!grid_sync(a, target, &s_ok)) return;
-            // one wave per owner column: exclusive scan over the wave tiles with a running carry; lane 0 publishes the bucket size
-            for (uint32_t g = (uint32_t)wave; g < P; g += (uint32_t)n_waves) {
-                uint32_t carry = 0;
-                for (int64_t t0 = 0; t0 < n_wt; t0 += 64) {
-                    const int64_t t = t0 + lane;
-                    const uint32_t c = (t < n_wt) ? a.tile_sums[t * P + g] : 0u;
-                    uint32_t incl = c;
-                    for (int off = 1; off < 64; off <<= 1) {
-                        const uint32_t v = __shfl_up(incl, off);
-                        if (lane >= off) incl += v;
-                    }
-                    if (t < n_wt) a.tile_sums[t * P + g] = carry + incl - c;
-                    carry += __shfl(incl, 63);
-                }
-                if (lane == 0) {
-                    a.bucket_counts[g] = (int64_t)carry;
-                    a.counts_host[a.n_layers + g] = (int64_t)carry;
-                }
-            }
-            if (!grid_sync(a, target, &s_ok)) return;
-            for (int64_t wt = wave; wt < n_wt; wt += n_waves) {
-                int64_t off = 0; // lane g: next free slot of bucket g for this wave tile
-                if ((uint32_t)lane < P) {
-                    int64_t b = 0;
-                    for (uint32_t g = 0; g < (uint32_t)lane; ++g) b += a.bucket_counts[g];
-                    off = b + (int64_t)a.tile_sums[wt * P + lane];
-                }
-                for (int j = 0; j < kItems; ++j) {
-                    const int64_t i = wt * kRouteTile + j * 64 + lane;
-                    const bool valid = i < n_src;
-                    const int64_t id = valid ? src[i] : 0;
-                    const uint32_t o = valid ? owner_of((uint64_t)id, P, a.pshift) : 0xFFFFFFFFu;
-                    int64_t dest = -1;
-                    for (uint32_t g = 0; g < P; ++g) {
-                        const uint64_t m = __ballot(o == g);
-                        const int64_t bg = __shfl(off, (int)g);
-                        if (o == g) dest = bg + __builtin_popcountll(m & ((1ull << lane) - 1ull));
-                        if ((uint32_t)lane == g) off += __builtin_popcountll(m);
-                    }
-                    if (valid) {
-                        a.bucketed[dest] = id;
-                        a.new_of_old[i] = (uint32_t)dest;
-                    }
-                }
-            }
-            if (!grid_sync(a, target, &s_ok)) return;
-            const int64_t n_nbr = n_dst * f;
-            int32_t* __restrict__ loc = a.nbr_local_out[l];
-            for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q < n_nbr; q += (int64_t)gridDim.x * kBlock) {
-                const int32_t o = loc[q];
-                if (o >= 0) loc[q] = (int32_t)a.new_of_old[o];
-            }
-            for (int64_t d = (int64_t)blockIdx.x * kBlock + threadIdx.x; d < n_dst; d += (int64_t)gridDim.x * kBlock)
-                a.dst_in_src[d] = (int32_t)a.new_of_old[d]; // the dst nodes are the first n_dst entries of the unbucketed list
-            return;
-        }
-        dst = src;
-        n_dst = n_src;
+        if (lane == 0) totals[g] = (int64_t)carry;
     }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int64_t acc = 0;
+        for (uint32_t g = 0; g < P; ++g) {
+            counts_out[g] = totals[g];
+            counts_host[g] = totals[g];
+            bases[g] = acc;
+            acc += totals[g];
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void bucket_scatter_kernel(const int64_t* __restrict__ src, const int64_t* __restrict__ n_src_dev, uint32_t P,
+                                                                int pshift, const uint32_t* __restrict__ wave_offsets, const int64_t* __restrict__ bases,
+                                                                int64_t* __restrict__ bucketed, uint32_t* __restrict__ new_of_old) {
+    const int lane = threadIdx.x & 63;
+    const int64_t n_src = *n_src_dev;
+    const int64_t n_wt = (n_src + kRouteTile - 1) / kRouteTile;
+    const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * kWavesPerBlock;
+    for (int64_t wt = wave; wt < n_wt; wt += n_waves) {
+        int64_t off = 0; // lane g: next free slot of bucket g for this wave tile
+        if ((uint32_t)lane < P) off = bases[lane] + (int64_t)wave_offsets[wt * P + lane];
+        for (int j = 0; j < kItems; ++j) {
+            const int64_t i = wt * kRouteTile + j * 64 + lane;
+            const bool valid = i < n_src;
+            const int64_t id = valid ? src[i] : 0;
+            const uint32_t o = valid ? owner_of((uint64_t)id, P, pshift) : 0xFFFFFFFFu;
+            int64_t dest = -1;
+            for (uint32_t g = 0; g < P; ++g) {
+                const uint64_t m = __ballot(o == g);
+                const int64_t bg = __shfl(off, (int)g);
+                if (o == g) dest = bg + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+                if ((uint32_t)lane == g) off += __builtin_popcountll(m);
+            }
+            if (valid) {
+                bucketed[dest] = id;
+                new_of_old[i] = (uint32_t)dest;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void bucket_reindex_kernel(const int64_t* __restrict__ n_dst_dev, int64_t n_dst_value, int fanout,
+                                                                const uint32_t* __restrict__ new_of_old, int32_t* __restrict__ nbr_local,
+                                                                int32_t* __restrict__ dst_in_src) {
+    const int64_t n_dst = n_dst_dev ? *n_dst_dev : n_dst_value;
+    const int64_t n_nbr = n_dst * fanout;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n_nbr; q += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t o = nbr_local[q];
+        if (o >= 0) nbr_local[q] = (int32_t)new_of_old[o];
+    }
+    for (int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; d < n_dst; d += (int64_t)gridDim.x * blockDim.x)
+        dst_in_src[d] = (int32_t)new_of_old[d]; // the dst nodes are the first n_dst entries of the unbucketed list
+}
+
+int grid1d(int64_t n, int block, int cap) {
+    int64_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
 }
 
 } // namespace
 
 struct coala_sampler {
     int device = 0;
-    const int64_t* indptr = nullptr;
-    const int64_t* indices = nullptr;
-    int64_t num_nodes = 0, num_edges = 0;
-    int max_grid = 0;                 // blocks of the persistent kernel: at most one per CU
+    Graph g{};
+    int64_t num_edges = 0;
     // workspace, grown on demand
     int64_t* nbr_global = nullptr;    uint64_t nbr_cap = 0;
-    long long* keys = nullptr;        uint32_t* minpos = nullptr; uint32_t* local_of_slot = nullptr; uint64_t table_cap = 0;
+    Table tb{};                       uint64_t table_cap = 0;
+    uint64_t clean_items = 0;         // the table is clean for a first layer of at most this many items (0 = unknown)
     uint32_t* slot_of_item = nullptr; uint64_t item_cap = 0;
-    uint32_t* tile_sums = nullptr;    uint64_t tile_cap = 0;
+    uint32_t* wave_counts = nullptr;  uint64_t wc_cap = 0;
     uint32_t* new_of_old = nullptr;   uint64_t noo_cap = 0;
-    unsigned long long* barrier = nullptr; // device counter, monotonic across calls
-    unsigned long long barrier_total = 0;
-    // pinned host ring: per call [kMaxLayers source counts][kMaxParts bucket sizes], an error flag, and an event recorded behind the kernel
+    unsigned long long* status = nullptr;  // [kMaxTiles] look-back status words (generation-tagged, never reset)
+    unsigned long long* ticket = nullptr;  // tile ticket counter, monotonic across launches
+    unsigned long long ticket_total = 0, scan_gen = 0;
+    int64_t* counts_dev = nullptr;         // [kMaxLayers + 1] source counts of the call in flight; then [kMaxParts] bucket bases
+    // pinned host ring: per call [kMaxLayers source counts][kMaxParts bucket sizes], and an event recorded behind the last kernel
     int64_t* counts_pinned = nullptr; // host pointer
     int64_t* counts_pinned_dev = nullptr;
-    int* error_pinned = nullptr;
-    int* error_pinned_dev = nullptr;
     hipEvent_t done[kRing] = {};
     int ring_layers[kRing] = {};
     int ring_parts[kRing] = {};
@@ -454,30 +425,16 @@ int coala_sampler_create(int device, const int64_t* indptr, const int64_t* indic
     coala_sampler* s = new (std::nothrow) coala_sampler();
     if (!s) return fail(COALA_ENOMEM, "out of host memory");
     s->device = device;
-    s->indptr = indptr;
-    s->indices = indices;
-    s->num_nodes = num_nodes;
+    s->g = Graph{indptr, indices, num_nodes};
     s->num_edges = num_edges;
-    hipDeviceProp_t prop;
-    int per_cu = 0;
-    if (hipGetDeviceProperties(&prop, device) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sample_layers_kernel, kBlock, 0) != hipSuccess || per_cu < 1) {
-        delete s;
-        return fail(COALA_EHIP, "cannot size the sampler's persistent kernel: %s", hipGetErrorString(hipGetLastError()));
-    }
-    // One block per CU at most: every block of the grid is resident at once (the grid barriers rely on it) with room to spare for
-    // whatever else runs on the GPU -- including the persistent kernel of another sampler (another process on the same GPU).
-    s->max_grid = prop.multiProcessorCount;
-    bool ok = hipMalloc((void**)&s->barrier, sizeof(unsigned long long)) == hipSuccess &&
-              hipMemset(s->barrier, 0, sizeof(unsigned long long)) == hipSuccess &&
+    bool ok = hipMalloc((void**)&s->status, kMaxTiles * sizeof(unsigned long long)) == hipSuccess &&
+              hipMemset(s->status, 0, kMaxTiles * sizeof(unsigned long long)) == hipSuccess &&
+              hipMalloc((void**)&s->ticket, sizeof(unsigned long long)) == hipSuccess &&
+              hipMemset(s->ticket, 0, sizeof(unsigned long long)) == hipSuccess &&
+              hipMalloc((void**)&s->counts_dev, (COALA_SAMPLER_MAX_LAYERS + 1 + kMaxParts) * sizeof(int64_t)) == hipSuccess &&
               hipHostMalloc((void**)&s->counts_pinned, kRing * kSlot * sizeof(int64_t), hipHostMallocMapped) == hipSuccess &&
-              hipHostGetDevicePointer((void**)&s->counts_pinned_dev, s->counts_pinned, 0) == hipSuccess &&
-              hipHostMalloc((void**)&s->error_pinned, sizeof(int), hipHostMallocMapped) == hipSuccess &&
-              hipHostGetDevicePointer((void**)&s->error_pinned_dev, s->error_pinned, 0) == hipSuccess;
-    if (ok) {
-        *s->error_pinned = 0;
-        for (int i = 0; i < kRing && ok; ++i) ok = hipEventCreateWithFlags(&s->done[i], hipEventDisableTiming) == hipSuccess;
-    }
+              hipHostGetDevicePointer((void**)&s->counts_pinned_dev, s->counts_pinned, 0) == hipSuccess;
+    for (int i = 0; i < kRing && ok; ++i) ok = hipEventCreateWithFlags(&s->done[i], hipEventDisableTiming) == hipSuccess;
     if (!ok || hipDeviceSynchronize() != hipSuccess) {
         coala_sampler_destroy(s);
         return fail(COALA_ENOMEM, "sampler set-up failed: %s", hipGetErrorString(hipGetLastError()));
@@ -490,11 +447,10 @@ int coala_sampler_destroy(coala_sampler_t* s) {
     if (!s) return COALA_OK;
     (void)hipSetDevice(s->device);
     (void)hipDeviceSynchronize();
-    void* ptrs[] = {s->nbr_global, s->keys, s->local_of_slot, s->slot_of_item, s->tile_sums, s->new_of_old, s->barrier};
+    void* ptrs[] = {s->nbr_global, s->tb.keys, s->tb.local_of_slot, s->slot_of_item, s->wave_counts, s->new_of_old, s->status, s->ticket, s->counts_dev};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (s->counts_pinned) (void)hipHostFree(s->counts_pinned);
-    if (s->error_pinned) (void)hipHostFree(s->error_pinned);
     for (int i = 0; i < kRing; ++i)
         if (s->done[i]) (void)hipEventDestroy(s->done[i]);
     delete s;
@@ -507,13 +463,12 @@ int coala_sampler_wait(coala_sampler_t* s, int64_t ticket, int64_t* n_src_host, 
         return fail(COALA_EINVAL, "ticket %lld is not one of the last %d calls", (long long)ticket, kRing);
     HIPCHK(hipSetDevice(s->device));
     const int slot = (int)((uint64_t)ticket % kRing);
-    HIPCHK(hipEventSynchronize(s->done[slot])); // the kernel behind this event stored the counts into pinned host memory
-    if (*s->error_pinned) return fail(COALA_EHIP, "the sampler kernel gave up at a grid barrier (a block of its grid never arrived)");
+    HIPCHK(hipEventSynchronize(s->done[slot])); // the kernels behind this event stored the counts into pinned host memory
     const int64_t* pin = s->counts_pinned + (size_t)slot * kSlot;
     if (n_src_host)
         for (int l = 0; l < s->ring_layers[slot]; ++l) n_src_host[l] = pin[l];
     if (bucket_counts_host)
-        for (int g = 0; g < s->ring_parts[slot]; ++g) bucket_counts_host[g] = pin[s->ring_layers[slot] + g];
+        for (int g = 0; g < s->ring_parts[slot]; ++g) bucket_counts_host[g] = pin[COALA_SAMPLER_MAX_LAYERS + g];
     return COALA_OK;
 }
 
@@ -545,66 +500,84 @@ int coala_sampler_sample(coala_sampler_t* s, const int64_t* seeds, int64_t n_see
     int rc;
     if ((rc = grow((void**)&s->nbr_global, &s->nbr_cap, max_nbr ? max_nbr : 1, sizeof(int64_t), st))) return rc;
     if ((rc = grow((void**)&s->slot_of_item, &s->item_cap, max_items ? max_items : 1, sizeof(uint32_t), st))) return rc;
-    if ((rc = grow((void**)&s->tile_sums, &s->tile_cap, std::max<uint64_t>(kMaxTiles, (wave_tiles + 1) * (uint64_t)(n_parts > 0 ? n_parts : 1)), sizeof(uint32_t), st))) return rc;
-    if (n_parts > 0 && (rc = grow((void**)&s->new_of_old, &s->noo_cap, (uint64_t)cap ? (uint64_t)cap : 1, sizeof(uint32_t), st))) return rc;
+    if (n_parts > 0) {
+        if ((rc = grow((void**)&s->wave_counts, &s->wc_cap, (wave_tiles + 1) * (uint64_t)n_parts, sizeof(uint32_t), st))) return rc;
+        if ((rc = grow((void**)&s->new_of_old, &s->noo_cap, (uint64_t)cap ? (uint64_t)cap : 1, sizeof(uint32_t), st))) return rc;
+    }
     if (table > s->table_cap) {
         HIPCHK(hipStreamSynchronize(st));
-        for (void** p : {(void**)&s->keys, (void**)&s->local_of_slot})
+        for (void** p : {(void**)&s->tb.keys, (void**)&s->tb.local_of_slot})
             if (*p) { HIPCHK(hipFree(*p)); *p = nullptr; }
-        HIPCHK(hipMalloc((void**)&s->keys, table * (sizeof(long long) + sizeof(uint32_t)))); // keys + first-position words
-        HIPCHK(hipMalloc((void**)&s->local_of_slot, table * sizeof(uint32_t)));
+        HIPCHK(hipMalloc((void**)&s->tb.keys, table * (sizeof(long long) + sizeof(uint32_t)))); // keys, then the first-position words
+        HIPCHK(hipMalloc((void**)&s->tb.local_of_slot, table * sizeof(uint32_t)));
         s->table_cap = table;
-        s->minpos = reinterpret_cast<uint32_t*>(s->keys + table);
+        s->tb.minpos = reinterpret_cast<uint32_t*>(s->tb.keys + table);
+        s->clean_items = 0;
     }
     const uint64_t ticket = s->calls;
     const int slot = (int)(ticket % kRing);
     if (ticket >= kRing) HIPCHK(hipEventSynchronize(s->done[slot])); // the ring slot's previous user has finished writing it
     int64_t* pin = s->counts_pinned + (size_t)slot * kSlot;
+    int64_t* pin_dev = s->counts_pinned_dev + (size_t)slot * kSlot;
     s->ring_layers[slot] = n_layers;
     s->ring_parts[slot] = n_parts;
     if (n_seeds == 0) {
         for (int l = 0; l < n_layers; ++l) pin[l] = 0;
-        for (int g = 0; g < n_parts; ++g) pin[n_layers + g] = 0;
+        for (int g = 0; g < n_parts; ++g) pin[COALA_SAMPLER_MAX_LAYERS + g] = 0;
         if (n_parts > 0) HIPCHK(hipMemsetAsync(bucketing->counts, 0, (size_t)n_parts * sizeof(int64_t), st));
     } else {
-        SampleArgs a{};
-        a.indptr = s->indptr;
-        a.indices = s->indices;
-        a.num_nodes = s->num_nodes;
-        a.seeds = seeds;
-        a.n_seeds = n_seeds;
-        a.n_layers = n_layers;
+        // the first layer's table: normally left clean by the previous call's last kernel
+        const uint64_t items0 = (uint64_t)n_seeds * (uint64_t)(fanouts[0] + 1);
+        if (s->clean_items == 0 || table_size((int64_t)items0) > table_size((int64_t)s->clean_items)) {
+            const uint32_t t0 = table_size((int64_t)items0);
+            HIPCHK(hipMemsetAsync(s->tb.keys, 0xFF, (size_t)t0 * sizeof(long long), st));
+            HIPCHK(hipMemsetAsync(s->tb.minpos, 0xFF, (size_t)t0 * sizeof(uint32_t), st));
+        }
+        const int64_t* n_dst_dev = nullptr;            // first layer: the seed count travels as a kernel argument
+        const int64_t* dst = seeds;
+        cap = n_seeds;
         for (int l = 0; l < n_layers; ++l) {
-            a.fanout[l] = fanouts[l];
-            a.src_out[l] = src_nodes_out[l];
-            a.nbr_local_out[l] = nbr_local_out[l];
+            const int f = fanouts[l];
+            const int64_t items_cap = cap * (f + 1);
+            int64_t* n_src_dev = s->counts_dev + l + 1;
+            const dim3 gs(grid1d(cap * (f < 16 ? 16 : f < 32 ? 32 : 64), kBlock, 8192)), blk(kBlock);
+            if (f < 16)
+                hipLaunchKernelGGL(sample_insert_kernel<16>, gs, blk, 0, st, s->g, dst, n_dst_dev, n_seeds, f, seed, step, l, s->nbr_global, s->tb, s->slot_of_item);
+            else if (f < 32)
+                hipLaunchKernelGGL(sample_insert_kernel<32>, gs, blk, 0, st, s->g, dst, n_dst_dev, n_seeds, f, seed, step, l, s->nbr_global, s->tb, s->slot_of_item);
+            else
+                hipLaunchKernelGGL(sample_insert_kernel<64>, gs, blk, 0, st, s->g, dst, n_dst_dev, n_seeds, f, seed, step, l, s->nbr_global, s->tb, s->slot_of_item);
+            const int tiles = grid1d(items_cap, kTile, kMaxTiles);
+            if ((++s->scan_gen & 0x3FFFFFFFull) == 0) { // 2^30 scans: the generation tag wraps -> clear the status words once
+                HIPCHK(hipMemsetAsync(s->status, 0, kMaxTiles * sizeof(unsigned long long), st));
+                s->scan_gen++;
+            }
+            hipLaunchKernelGGL(scan_assign_kernel, dim3(tiles), blk, 0, st, dst, s->nbr_global, n_dst_dev, n_seeds, f, s->slot_of_item, s->tb, s->status,
+                               s->ticket, s->ticket_total, s->scan_gen & 0x3FFFFFFFull, src_nodes_out[l], n_src_dev, pin_dev + l);
+            s->ticket_total += (unsigned long long)tiles;
+            const bool last = l + 1 == n_layers;
+            const int64_t clear_cap = last ? (int64_t)table_size((int64_t)items0) : (int64_t)table_size(items_cap * (fanouts[l + 1] + 1));
+            hipLaunchKernelGGL(relabel_clear_kernel, dim3(grid1d(std::max<int64_t>(cap * f, clear_cap), kBlock, 4096)), blk, 0, st, n_dst_dev, n_seeds, f,
+                               s->slot_of_item, s->tb, nbr_local_out[l], last ? (const int64_t*)nullptr : (const int64_t*)n_src_dev,
+                               last ? 0 : fanouts[l + 1], (int64_t)items0);
+            if (last && n_parts > 0) {
+                const uint32_t P = (uint32_t)n_parts;
+                const int pshift = ilog2_exact((uint64_t)n_parts);
+                int64_t* bases = s->counts_dev + COALA_SAMPLER_MAX_LAYERS + 1;
+                const dim3 gw(grid1d(((items_cap + kRouteTile - 1) / kRouteTile) * 64, kBlock, 4096));
+                hipLaunchKernelGGL(bucket_count_kernel, gw, blk, 0, st, src_nodes_out[l], n_src_dev, P, pshift, s->wave_counts);
+                hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(64 * (n_parts < 16 ? n_parts : 16)), 0, st, s->wave_counts, n_src_dev, P,
+                                   bucketing->counts, pin_dev + COALA_SAMPLER_MAX_LAYERS, bases);
+                hipLaunchKernelGGL(bucket_scatter_kernel, gw, blk, 0, st, src_nodes_out[l], n_src_dev, P, pshift, s->wave_counts, bases,
+                                   bucketing->bucketed_nodes, s->new_of_old);
+                hipLaunchKernelGGL(bucket_reindex_kernel, dim3(grid1d(cap * f, kBlock, 4096)), blk, 0, st, n_dst_dev, n_seeds, f, s->new_of_old,
+                                   nbr_local_out[l], bucketing->dst_in_src);
+            }
+            dst = src_nodes_out[l];
+            n_dst_dev = n_src_dev;
+            cap = items_cap;
         }
-        a.seed = seed;
-        a.step = step;
-        a.nbr = s->nbr_global;
-        a.keys = s->keys;
-        a.minpos = s->minpos;
-        a.local_of_slot = s->local_of_slot;
-        a.slot_of_item = s->slot_of_item;
-        a.tile_sums = s->tile_sums;
-        a.counts_host = s->counts_pinned_dev + (size_t)slot * kSlot;
-        a.barrier = s->barrier;
-        a.barrier_base = s->barrier_total;
-        a.error = s->error_pinned_dev;
-        a.n_parts = n_parts;
-        a.pshift = n_parts > 0 ? ilog2_exact((uint64_t)n_parts) : -1;
-        if (n_parts > 0) {
-            a.bucketed = bucketing->bucketed_nodes;
-            a.bucket_counts = bucketing->counts;
-            a.dst_in_src = bucketing->dst_in_src;
-            a.new_of_old = s->new_of_old;
-        }
-        // grid: enough waves for the widest sampling phase (16 lanes per destination node), at most one block per CU
-        const int64_t want = (cap / (int64_t)(fanouts[n_layers - 1] + 1) * 16 + kBlock * 2 - 1) / (kBlock * 2);
-        const int grid = (int)std::max<int64_t>(16, std::min<int64_t>(s->max_grid, want));
-        const int barriers = 1 + 4 * n_layers - (n_parts > 0 ? 0 : 1) + (n_parts > 0 ? 3 : 0);
-        s->barrier_total += (unsigned long long)grid * (unsigned long long)barriers;
-        hipLaunchKernelGGL(sample_layers_kernel, dim3(grid), dim3(kBlock), 0, st, a);
+        s->clean_items = items0;
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(s->done[slot], st));

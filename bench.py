@@ -276,7 +276,10 @@ def _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, dev
     g = torch.Generator().manual_seed(0)
     train_ids = torch.randperm(n_train, generator=g)
     steps_per_epoch = n_train // (args.batch * world) - 1  # COALA_GNN_DataLoader.py:141
-    sampler = NeighborSampler(fanout, seed=args.seed)
+    # N>1 over the native exchange: the sampler delivers the input nodes already bucketed by owner, so the fetch needs no routing
+    # pass and no un-permute (rows are received in place)
+    bucket = world if (world > 1 and backend != "isolated") else 0
+    sampler = NeighborSampler(fanout, seed=args.seed, bucket_by_owner=bucket)
     graph = sampler.make_graph(indptr, indices)
     log(f"graph {args.rows} nodes / {indices.numel()} edges built in {time.time() - t0:.1f}s")
 
@@ -294,28 +297,28 @@ def _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, dev
         lo = ((step % max(steps_per_epoch, 1)) * world + rank) * args.batch
         return train_ids[lo: lo + args.batch].to(device)
 
-    def ids_for(step):
+    def ids_for(step):  # -> the loader's batch tuple (input_nodes, seeds, blocks); the micro-benchmark modes carry ids only
         if args.mode == "minibatch":
-            return sampler.sample(graph, seeds_for(step))[0]
+            return sampler.sample(graph, seeds_for(step))
         gen = torch.Generator(device=device).manual_seed(1000 * step + rank if args.mode == "allmiss" else rank)
-        return torch.randperm(args.rows, generator=gen, device=device)[:max_rows]
+        return (torch.randperm(args.rows, generator=gen, device=device)[:max_rows],)
 
     # ---------------------------------------------------------------- untimed: bring the cache to its steady state
     t0 = time.time()
     for s in range(args.prewarm):
-        manager.fetch_feature((ids_for(s),))
+        manager.fetch_feature(ids_for(s))
     torch.cuda.synchronize()
     log(f"prewarm {args.prewarm} minibatches in {time.time() - t0:.1f}s")
     batches = [ids_for(args.prewarm + s) for s in range(args.warmup + args.steps)]  # resident in HBM before timing
     torch.cuda.synchronize()
 
     for s in range(args.warmup):
-        manager.fetch_feature((batches[s],))
+        manager.fetch_feature(batches[s])
     torch.cuda.synchronize()
     # parity self-check on every rank, untimed: the rows this path just delivered == the synthetic table's formula, bit for bit.
     # (At N>1 this is the first time the exchange runs over real RCCL links: a wrong row must stop the run, not be timed.)
-    chk_ids = batches[0]
-    got = manager.fetch_feature((chk_ids,))[-1]
+    chk_ids = batches[0][0]
+    got = manager.fetch_feature(batches[0])[-1]
     want = feature_rows_torch(chk_ids, args.dim, args.seed)
     if not torch.equal(got, want):
         bad = int((got != want).any(dim=1).sum())
@@ -336,7 +339,7 @@ def _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, dev
     t_start = time.perf_counter()
     rows_done = 0
     for s in range(args.warmup, args.warmup + args.steps):
-        out = manager.fetch_feature((batches[s],))[-1]
+        out = manager.fetch_feature(batches[s])[-1]
         rows_done += out.shape[0]
     torch.cuda.synchronize()
     if world > 1:
@@ -448,7 +451,7 @@ def _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, dev
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and host_array is not None:
-        cpu_baseline = run_cpu_baseline(args, host_array, batches[args.warmup:], fanout, graph, seeds_for)
+        cpu_baseline = run_cpu_baseline(args, host_array, [b[0] for b in batches[args.warmup:]], fanout, graph, seeds_for)
 
     if rank == 0:
         line = {
@@ -465,6 +468,7 @@ def _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, dev
                        "exchange_transport": getattr(manager, "exchange_kind", None) if world > 1 else None,
                        "rccl_ranks": (getattr(manager.exchange, "rccl_ranks", None) or
                                       (dist.get_world_size(comm.nccl_cache_gather) if not single_dev else None)) if world > 1 else None,
+                       "input_nodes": "bucketed by owner by the sampler (no routing pass, rows received in place)" if bucket else "sampler order",
                        "parity_check": "rows of one warm-up minibatch == synthetic table formula, bit-exact, on every rank", "cold_tier": "HBM" if args.cold_tier == "hbm" else ("pinned host, owner-partitioned" if cold_partitioned else "pinned host"),
                        "prewarm_steps": args.prewarm, "rows_scale_factor": rows_scale,
                        "steps_per_epoch": steps_per_epoch,
@@ -547,7 +551,7 @@ def run_fanout_leg(args, comm, graph, table, device, fanout, backend, cold_parti
     """Fetch-only rate of the same table / graph / cache size at another fan-out (own cache handle, own sampler)."""
     from COALA_GNN.COALA_GNN_Manager import COALA_GNN_Manager
     from COALA_GNN.sampler import NeighborSampler
-    smp = NeighborSampler(fanout, seed=args.seed)
+    smp = NeighborSampler(fanout, seed=args.seed, bucket_by_owner=world if (world > 1 and backend != "isolated") else 0)
     mgr = COALA_GNN_Manager(node_distributor=None, num_ssds=1, page_size=args.dim * 4, num_elems=1024, ssd_read_offset=0,
                             cache_size=args.cache_mb, batch_size=args.batch, fan_out=fanout, dim=args.dim,
                             MPI_comm_manager=comm, device=device, cache_backend=backend, sim_buf=table, num_rows=args.rows,
@@ -556,9 +560,9 @@ def run_fanout_leg(args, comm, graph, table, device, fanout, backend, cold_parti
 
     def ids_for(step):
         lo = ((step % max(steps_per_epoch, 1)) * world + rank) * args.batch
-        return smp.sample(graph, train_ids[lo: lo + args.batch].to(device))[0]
+        return smp.sample(graph, train_ids[lo: lo + args.batch].to(device))
     for s_ in range(prewarm):
-        mgr.fetch_feature((ids_for(s_),))
+        mgr.fetch_feature(ids_for(s_))
     batches = [ids_for(prewarm + s_) for s_ in range(steps)]
     torch.cuda.synchronize()
     mgr.COALA_GNN_Cache.stats(reset=True)
@@ -568,7 +572,7 @@ def run_fanout_leg(args, comm, graph, table, device, fanout, backend, cold_parti
     t0 = time.perf_counter()
     rows = 0
     for b in batches:
-        rows += mgr.fetch_feature((b,))[-1].shape[0]
+        rows += mgr.fetch_feature(b)[-1].shape[0]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -44,6 +44,32 @@ class CSCGraph(object):
             pass
 
 
+class _MeanAggregate(torch.autograd.Function):
+    """out[d] = mean of h_src[nbr[d, j]] over the valid j (coala_block_mean_aggregate): one kernel forward, one backward."""
+
+    @staticmethod
+    def forward(ctx, h_src, nbr):
+        h = h_src.contiguous()
+        n_dst, fanout = nbr.shape
+        out = torch.empty((n_dst, h.shape[1]), dtype=torch.float32, device=h.device)
+        _capi.check(_lib.coala_block_mean_aggregate(h.device.index or 0, nbr.data_ptr(), h.data_ptr(), out.data_ptr(), n_dst, fanout, h.shape[1],
+                                                    current_stream()))
+        ctx.save_for_backward(nbr)
+        ctx.src_shape = h.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        if not ctx.needs_input_grad[0]:
+            return None, None
+        (nbr,) = ctx.saved_tensors
+        g = grad_out.contiguous()
+        grad_src = torch.zeros(ctx.src_shape, dtype=torch.float32, device=g.device)
+        _capi.check(_lib.coala_block_mean_aggregate_backward(g.device.index or 0, nbr.data_ptr(), g.data_ptr(), grad_src.data_ptr(), nbr.shape[0],
+                                                             nbr.shape[1], g.shape[1], current_stream()))
+        return grad_src, None
+
+
 class Block(object):
     """One message-flow block in fixed-stride form: dst node d aggregates src rows nbr[d, j] >= 0.
     The first num_dst source nodes ARE the destination nodes (DGL's to_block convention)."""
@@ -96,7 +122,13 @@ class Block(object):
         return self
 
     def mean_aggregate(self, h_src):
-        """Mean of the sampled neighbours' rows for every dst node: fp32 [num_dst, dim] (GraphSAGE 'mean')."""
+        """Mean of the sampled neighbours' rows for every dst node: fp32 [num_dst, dim] (GraphSAGE 'mean').  Native kernel for
+        fp32 rows on the GPU (fan-out <= 32); plain torch otherwise."""
+        if h_src.is_cuda and h_src.dtype == torch.float32 and self.nbr.is_cuda and self.nbr.is_contiguous() and self.nbr.shape[1] <= 32:
+            return _MeanAggregate.apply(h_src, self.nbr)
+        return self.mean_aggregate_torch(h_src)
+
+    def mean_aggregate_torch(self, h_src):
         valid = self.nbr >= 0
         idx = self.nbr.clamp_min(0).to(torch.int64)
         g = h_src[idx] * valid.unsqueeze(-1).to(h_src.dtype)

@@ -97,6 +97,8 @@ SYMBOLS = {
     "coala_sampler_destroy": (_I, [_VP]),
     "coala_sampler_sample": (_I, [_VP, _VP, _I64, C.POINTER(C.c_int32), _I, _U64, _U64, C.POINTER(_VP), C.POINTER(_VP),
                              C.POINTER(_I64), C.POINTER(SamplerBucketing), C.POINTER(_I64), _VP]),
+    "coala_block_mean_aggregate": (_I, [_I, _VP, _VP, _VP, _I64, _I, _I, _VP]),
+    "coala_block_mean_aggregate_backward": (_I, [_I, _VP, _VP, _VP, _I64, _I, _I, _VP]),
     "coala_sampler_wait": (_I, [_VP, _I64, C.POINTER(_I64), C.POINTER(_I64)]),
     "coala_shm_open": (_I, [C.c_char_p, _U64, _I, _I, C.POINTER(_VP)]),
     "coala_shm_host_ptr": (_VP, [_VP]),

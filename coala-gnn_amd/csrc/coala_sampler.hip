@@ -360,6 +360,55 @@ __global__ __launch_bounds__(kBlock) void bucket_reindex_kernel(const int64_t* _
         dst_in_src[d] = (int32_t)new_of_old[d]; // the dst nodes are the first n_dst entries of the unbucketed list
 }
 
+// ---------------------------------------------------------------------------------------------------------- block ops
+// The one dense-side primitive a consumer of these blocks needs (DGL's SAGEConv "mean" reduces to it): out[d] = mean of the rows
+// h_src[nbr[d, j]] over the valid j.  One wave per destination row, 16-B accesses, the neighbour indices read once per wave.
+// Replaces gather -> mask -> sum -> divide in eager torch (four passes over a [n_dst, fanout, dim] intermediate).
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void mean_aggregate_kernel(const int32_t* __restrict__ nbr, const float* __restrict__ h_src,
+                                                                float* __restrict__ out, int64_t n_dst, int fanout, int dim) {
+    typedef float vf __attribute__((ext_vector_type(VEC)));
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * kWavesPerBlock;
+    const int units = dim / VEC;
+    for (int64_t d = wave; d < n_dst; d += n_waves) {
+        const int32_t mine = lane < fanout ? nbr[d * fanout + lane] : -1; // fan-out <= 32: one load per wave
+        const int cnt = __builtin_popcountll(__ballot(mine >= 0));
+        const float inv = cnt ? 1.0f / (float)cnt : 0.0f;
+        for (int u0 = 0; u0 < units; u0 += 64) {
+            const int u = u0 + lane;
+            vf acc = vf(0.0f);
+            for (int j = 0; j < fanout; ++j) {
+                const int32_t idx = __shfl(mine, j);
+                if (idx >= 0 && u < units) acc += *reinterpret_cast<const vf*>(h_src + (int64_t)idx * dim + (int64_t)u * VEC);
+            }
+            if (u < units) *reinterpret_cast<vf*>(out + d * dim + (int64_t)u * VEC) = acc * inv;
+        }
+    }
+}
+
+// grad_src[nbr[d, j]] += grad_out[d] / cnt[d]   (grad_src zeroed by the caller; hardware float atomics: summation order varies)
+__global__ __launch_bounds__(kBlock) void mean_aggregate_backward_kernel(const int32_t* __restrict__ nbr, const float* __restrict__ grad_out,
+                                                                         float* __restrict__ grad_src, int64_t n_dst, int fanout, int dim) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * kWavesPerBlock;
+    for (int64_t d = wave; d < n_dst; d += n_waves) {
+        const int32_t mine = lane < fanout ? nbr[d * fanout + lane] : -1;
+        const int cnt = __builtin_popcountll(__ballot(mine >= 0));
+        if (!cnt) continue;
+        const float inv = 1.0f / (float)cnt;
+        for (int c = lane; c < dim; c += 64) {
+            const float g = grad_out[d * dim + c] * inv;
+            for (int j = 0; j < fanout; ++j) {
+                const int32_t idx = __shfl(mine, j);
+                if (idx >= 0) unsafeAtomicAdd(grad_src + (int64_t)idx * dim + c, g);
+            }
+        }
+    }
+}
+
 int grid1d(int64_t n, int block, int cap) {
     int64_t g = (n + block - 1) / block;
     if (g < 1) g = 1;
@@ -454,6 +503,31 @@ int coala_sampler_destroy(coala_sampler_t* s) {
     for (int i = 0; i < kRing; ++i)
         if (s->done[i]) (void)hipEventDestroy(s->done[i]);
     delete s;
+    return COALA_OK;
+}
+
+int coala_block_mean_aggregate(int device, const int32_t* nbr, const float* h_src, float* out, int64_t n_dst, int fanout, int dim, void* stream) {
+    if (n_dst < 0 || fanout < 1 || fanout > 32 || dim < 1) return fail(COALA_EINVAL, "bad block shape (fan-out 1..32)");
+    if (n_dst == 0) return COALA_OK;
+    if (!nbr || !h_src || !out) return fail(COALA_EINVAL, "null buffer");
+    HIPCHK(hipSetDevice(device));
+    const dim3 grid(grid1d(n_dst * 64, kBlock, 8192)), blk(kBlock);
+    const bool v4 = dim % 4 == 0 && ((reinterpret_cast<uintptr_t>(h_src) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0;
+    if (v4) hipLaunchKernelGGL(mean_aggregate_kernel<4>, grid, blk, 0, (hipStream_t)stream, nbr, h_src, out, n_dst, fanout, dim);
+    else hipLaunchKernelGGL(mean_aggregate_kernel<1>, grid, blk, 0, (hipStream_t)stream, nbr, h_src, out, n_dst, fanout, dim);
+    HIPCHK(hipGetLastError());
+    return COALA_OK;
+}
+
+int coala_block_mean_aggregate_backward(int device, const int32_t* nbr, const float* grad_out, float* grad_src, int64_t n_dst, int fanout,
+                                        int dim, void* stream) {
+    if (n_dst < 0 || fanout < 1 || fanout > 32 || dim < 1) return fail(COALA_EINVAL, "bad block shape (fan-out 1..32)");
+    if (n_dst == 0) return COALA_OK;
+    if (!nbr || !grad_out || !grad_src) return fail(COALA_EINVAL, "null buffer");
+    HIPCHK(hipSetDevice(device));
+    hipLaunchKernelGGL(mean_aggregate_backward_kernel, dim3(grid1d(n_dst * 64, kBlock, 8192)), dim3(kBlock), 0, (hipStream_t)stream, nbr, grad_out,
+                       grad_src, n_dst, fanout, dim);
+    HIPCHK(hipGetLastError());
     return COALA_OK;
 }
 

@@ -294,6 +294,14 @@ int coala_sampler_sample(coala_sampler_t* s, const int64_t* seeds, int64_t n_see
 /* Counts of an earlier call (its ticket): n_src_host[n_layers] and, when it bucketed, bucket_counts_host[n_parts] (either NULL). */
 int coala_sampler_wait(coala_sampler_t* s, int64_t ticket, int64_t* n_src_host, int64_t* bucket_counts_host);
 
+/* Block op for the consumer of these blocks (the native Block objects stand where DGL blocks stand in
+ * examples/sbatch_ssd_gnn_train.py:138-141; dgl.nn.SAGEConv's "mean" reduces to this): out[d, :] = mean over the valid j of
+ * h_src[nbr[d, j], :]; nbr int32 [n_dst, fanout] (-1 padded, fan-out <= 32), fp32 rows of `dim` floats.  The backward adds
+ * grad_out[d] / count(d) into grad_src[nbr[d, j]] with hardware float atomics (grad_src zeroed by the caller). */
+int coala_block_mean_aggregate(int device, const int32_t* nbr, const float* h_src, float* out, int64_t n_dst, int fanout, int dim, void* stream);
+int coala_block_mean_aggregate_backward(int device, const int32_t* nbr, const float* grad_out, float* grad_src, int64_t n_dst, int fanout,
+                                        int dim, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Shared pinned-host ("UVA") region.  Replaces SharedUVAManager (COALA_GNN_Modules/shared_UVA.cuh:26-115):
  * creator shm_open+ftruncate, everybody mmap + hipHostRegister + hipHostGetDevicePointer.  The MPI barrier between

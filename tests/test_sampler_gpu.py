@@ -179,3 +179,30 @@ def test_sampler_async_tickets(hiplib):
     with pytest.raises(RuntimeError, match="ticket"):
         _capi.check(L.coala_sampler_wait(g._h, 99, None, None))
     g.close()
+
+
+@pytest.mark.parametrize("dim,fan", [(1024, 5), (128, 10), (100, 15), (19, 3)])
+def test_native_mean_aggregate_matches_torch(hiplib, dim, fan):
+    """Block.mean_aggregate: the native forward / backward kernels against the plain torch fp32 formulation of the same op
+    (tolerance 1e-5 relative: the summation order differs; the backward uses hardware float atomics)."""
+    import torch
+    from COALA_GNN.sampler import NeighborSampler
+    from COALA_GNN.synthetic import powerlaw_csc
+    indptr, indices = powerlaw_csc(8000, 6.0, seed=2, device="cuda")
+    sampler = NeighborSampler([fan, fan], seed=1)
+    g = sampler.make_graph(indptr, indices)
+    _, _, blocks = sampler.sample(g, torch.arange(0, 8000, 23, device="cuda"))
+    for b in blocks:
+        h = torch.rand(b.num_src, dim, device="cuda", requires_grad=True)
+        h2 = h.detach().clone().requires_grad_(True)
+        got = b.mean_aggregate(h)
+        want = b.mean_aggregate_torch(h2)
+        assert got.shape == want.shape and torch.allclose(got, want, rtol=1e-5, atol=1e-6)
+        w = torch.rand_like(got)
+        (got * w).sum().backward()
+        (want * w).sum().backward()
+        assert torch.allclose(h.grad, h2.grad, rtol=1e-5, atol=1e-6)
+        # a source tensor that needs no gradient (the input features) costs no backward pass
+        feat = torch.rand(b.num_src, dim, device="cuda")
+        assert not b.mean_aggregate(feat).requires_grad
+    g.close()

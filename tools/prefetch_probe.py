@@ -1,6 +1,11 @@
+"""The prefetching loader with and without a training load: host-side split of a step (consumer wait, producer stages).
+Development tool.  K2_GRID=<blocks> selects the development library and its cold-fill grid knob; ONLY_TRAIN=1 skips the no-training leg."""
 import os, sys, time, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "coala-gnn_amd"))
+if os.environ.get("K2_GRID"):
+    os.environ["COALA_HIP_LIB"] = os.path.join(ROOT, "coala-gnn_amd", "lib", "libcoala_hip_dev.so")
+    os.environ["COALA_K2_GRID"] = os.environ["K2_GRID"]
 import numpy as np, torch
 from COALA_GNN import MPI_Comm_Manager, Node_Distributor, SSD_INFO, COALA_GNN_DataLoader
 from COALA_GNN.harness import SageMean
@@ -20,10 +25,10 @@ np.save(files[0], color); np.save(files[1], tk); np.save(files[2], sc)
 ids = torch.randperm(int(0.6 * rows), generator=torch.Generator().manual_seed(0))[: 1200 * batch]
 sampler = NeighborSampler(fan, seed=0)
 g = sampler.make_graph(indptr, indices, ndata={"labels": (torch.arange(rows, device="cuda") * 7) % 19})
-for train in (False, True):
+for train in ((True,) if os.environ.get("ONLY_TRAIN") else (False, True)):
     nd = Node_Distributor(comm, ids, batch, *files, parsing_method="baseline")
-    loader = COALA_GNN_DataLoader(SSD_INFO(1, 4096, 1024, 0), nd, g, sampler, batch, dim, fan, 4096, "cuda:0", cache_backend="isolated", sim_buf=table, num_rows=rows, prefetch=2)
-    model = SageMean(dim, 128, 19).cuda(); opt = torch.optim.Adam(model.parameters(), 1e-3); lossf = torch.nn.CrossEntropyLoss()
+    loader = COALA_GNN_DataLoader(SSD_INFO(1, 4096, 1024, 0), nd, g, sampler, batch, dim, fan, 4096, "cuda:0", cache_backend="isolated", sim_buf=table, num_rows=rows, prefetch=int(os.environ.get("PREFETCH", "2")))
+    model = SageMean(dim, 128, 19).cuda(); opt = torch.optim.Adam(model.parameters(), 1e-3, fused=bool(int(os.environ.get("FUSED_ADAM", "1")))); lossf = torch.nn.CrossEntropyLoss()
     n = 0; wait = 0.0; t_train = 0.0
     ST = {}
     def wrap(obj, name, key):

@@ -619,6 +619,10 @@ def run_epoch_leg(args, comm, graph, sampler, table, device, fanout, steps_per_e
     # serial first: at N>1 the prefetching loader (exchange and DDP collectives issued from two host threads) only runs behind
     # a serial leg that completed on every rank
     modes = [("serial", 0), ("prefetch", 2)]
+    if os.environ.get("COALA_SWITCH_INTERVAL"):  # experiment: GIL hand-off latency between the producer and the consumer thread
+        sys.setswitchinterval(float(os.environ["COALA_SWITCH_INTERVAL"]))
+    if os.environ.get("COALA_EPOCH_MODES"):
+        modes = [m for m in modes if m[0] in os.environ["COALA_EPOCH_MODES"].split(",")]
     if world > 1 and not args.epoch_prefetch_multi:
         modes = modes[:1]
         out["prefetch"] = None

@@ -68,10 +68,22 @@ class COALA_GNN_Node_Distribution_Scheduler(object):
             if self.cache_meta_gather_thread is not None:
                 self.cache_meta_gather_thread.result()
                 nd.cache_color_db_header = int((nd.cache_color_db_header + 1) % 2)
-            self.ssd_gnn_manager.COALA_GNN_Cache.get_cache_data(self.cache_meta_tensor.data_ptr(),
-                                                                self.cache_meta_tensor.numel())
+            cache = self.ssd_gnn_manager.COALA_GNN_Cache
             self.cache_color_gathered_header = int((nd.cache_color_db_header + 1) % 2)
-            self.cache_meta_gather_thread = self._meta_pool.submit(nd.gather_cache_meta, self.cache_meta_tensor)
+            if hasattr(cache, "get_cache_data_async"):
+                # The snapshot is taken at THIS point of the stream (as the reference's synchronous read, :56-58), but nobody on this
+                # thread needs the numbers: the helper that gathers them across ranks waits for the copy.  A blocking read here held
+                # up the thread that enqueues the next fetch for as long as the previous fetch still ran (an idle gap on the fetch
+                # stream every refresh_counter steps: tools/fetch_gap_probe.py).
+                cache.get_cache_data_async(self.cache_meta_tensor.numel())
+
+                def finish_and_gather(t=self.cache_meta_tensor):
+                    cache.get_cache_data_finish(t.data_ptr(), t.numel())
+                    nd.gather_cache_meta(t)
+                self.cache_meta_gather_thread = self._meta_pool.submit(finish_and_gather)
+            else:
+                cache.get_cache_data(self.cache_meta_tensor.data_ptr(), self.cache_meta_tensor.numel())
+                self.cache_meta_gather_thread = self._meta_pool.submit(nd.gather_cache_meta, self.cache_meta_tensor)
 
         if comm.is_master and not is_last:
             self.distribute_thread = self._dist_pool.submit(nd.parse_domain_training_nodes, self.cache_color_gathered_header)

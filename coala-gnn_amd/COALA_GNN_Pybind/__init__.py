@@ -205,6 +205,16 @@ class _CacheBase:
         n = self.num_color if n_entries is None else int(n_entries)
         check(_lib.coala_cache_color_counts(self._h, int(ret_i_ptr), n, current_stream()))
 
+    def get_cache_data_async(self, n_entries=None):
+        """Enqueue the snapshot of the colour counters at this point of the current stream; no host wait (see get_cache_data_finish)."""
+        n = self.num_color if n_entries is None else int(n_entries)
+        check(_lib.coala_cache_color_counts_async(self._h, n, current_stream()))
+
+    def get_cache_data_finish(self, ret_i_ptr, n_entries=None):
+        """Wait for the pending snapshot (only for it) and store it at ret_i_ptr; callable from a helper thread."""
+        n = self.num_color if n_entries is None else int(n_entries)
+        check(_lib.coala_cache_color_counts_finish(self._h, int(ret_i_ptr), n))
+
     def stats(self, reset=False):
         hit, miss, bad = C.c_uint64(), C.c_uint64(), C.c_uint64()
         check(_lib.coala_cache_stats(self._h, C.byref(hit), C.byref(miss), C.byref(bad), int(reset), current_stream()))

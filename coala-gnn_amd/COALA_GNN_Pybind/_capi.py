@@ -79,6 +79,8 @@ SYMBOLS = {
     "coala_cache_fetch_distributed": (_I, [_VP, _VP, _VP, _VP, _I64, _VP]),
     "coala_cache_fetch_distributed_bucketed": (_I, [_VP, _VP, _VP, _VP, _I64, _VP, _VP]),
     "coala_cache_color_counts": (_I, [_VP, _VP, C.c_int32, _VP]),
+    "coala_cache_color_counts_async": (_I, [_VP, C.c_int32, _VP]),
+    "coala_cache_color_counts_finish": (_I, [_VP, _VP, C.c_int32]),
     "coala_cache_stats": (_I, [_VP, C.POINTER(_U64), C.POINTER(_U64), C.POINTER(_U64), _I, _VP]),
     "coala_cache_dump": (_I, [_VP, _VP, _VP, _VP, _VP]),
     "coala_cache_profile": (_I, [_VP, C.POINTER(CacheProfile), _I]),

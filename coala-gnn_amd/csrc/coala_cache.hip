@@ -694,6 +694,9 @@ struct coala_cache {
                                           // fill took 1.8 ms instead of 0.22 ms, and the prefetching epoch 11.7 s instead of 9.2 s.
                                           // Full grid: 53.7 GB/s; 8 blocks: 43.1 GB/s.  COALA_K2_GRID overrides.
     int32_t* color_pin = nullptr;         // pinned staging for coala_cache_color_counts
+    int32_t* color_pin_async = nullptr;   // pinned staging + event of a pending coala_cache_color_counts_async
+    hipEvent_t color_ev = nullptr;
+    int32_t color_pending = -1;           // entries of the pending snapshot, -1 = none
     int64_t open_batch_rows = -1;         // rows of a batch that was probed (serve_probe) and still waits for its fills
     std::vector<std::pair<int64_t, int64_t>> open_filled; // position ranges of the open batch already handed to a fill (sorted)
     int64_t open_filled_rows = 0;
@@ -954,6 +957,8 @@ int coala_cache_destroy(coala_cache_t* h) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->color_pin) (void)hipHostFree(h->color_pin);
+    if (h->color_pin_async) (void)hipHostFree(h->color_pin_async);
+    if (h->color_ev) (void)hipEventDestroy(h->color_ev);
     delete h;
     return COALA_OK;
 }
@@ -1237,6 +1242,39 @@ int coala_cache_color_counts(coala_cache_t* h, int32_t* dst, int32_t n_entries, 
     HIPCHK(hipMemcpyAsync(h->color_pin, h->d.color_counters, (size_t)n_entries * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     memcpy(dst, h->color_pin, (size_t)n_entries * 4);
+    return COALA_OK;
+}
+
+// The same snapshot without a host wait at the point of the call: _async enqueues the copy on `stream` (same position in the stream
+// as the synchronous call) and returns; _finish, from any thread, waits for exactly that copy and hands the counters over.  The
+// loader's scheduler reads the counters every refresh_counter steps and only feeds them to a helper thread: blocking the thread
+// that enqueues the next fetch for the ~1.5 ms the previous fetch still runs cost an idle gap on the fetch stream every time.
+int coala_cache_color_counts_async(coala_cache_t* h, int32_t n_entries, void* stream) {
+    if (!h) return fail(COALA_EINVAL, "null argument");
+    if (n_entries < 0 || n_entries > h->cfg.num_colors + 1) return fail(COALA_EINVAL, "n_entries=%d exceeds num_colors+1=%d", n_entries, h->cfg.num_colors + 1);
+    if (h->color_pending >= 0) return fail(COALA_EINVAL, "a colour-counter snapshot is already pending: call coala_cache_color_counts_finish first");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    if (h->d.color_counters) {
+        if (!h->color_pin_async) HIPCHK(hipHostMalloc((void**)&h->color_pin_async, ((size_t)h->cfg.num_colors + 1) * 4, hipHostMallocDefault));
+        if (!h->color_ev) HIPCHK(hipEventCreateWithFlags(&h->color_ev, hipEventDisableTiming));
+        HIPCHK(hipMemcpyAsync(h->color_pin_async, h->d.color_counters, (size_t)n_entries * 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+        HIPCHK(hipEventRecord(h->color_ev, (hipStream_t)stream));
+    }
+    h->color_pending = n_entries;
+    return COALA_OK;
+}
+
+int coala_cache_color_counts_finish(coala_cache_t* h, int32_t* dst, int32_t n_entries) {
+    if (!h || !dst) return fail(COALA_EINVAL, "null argument");
+    if (h->color_pending < 0 || n_entries != h->color_pending) return fail(COALA_EINVAL, "no pending snapshot of %d entries", n_entries);
+    if (!h->d.color_counters) {
+        memset(dst, 0, (size_t)n_entries * 4);
+    } else {
+        HIPCHK(hipSetDevice(h->cfg.device));
+        HIPCHK(hipEventSynchronize(h->color_ev));
+        memcpy(dst, h->color_pin_async, (size_t)n_entries * 4);
+    }
+    h->color_pending = -1;
     return COALA_OK;
 }
 

@@ -206,6 +206,10 @@ int coala_comm_profile(coala_comm_t* c, int enable, coala_comm_profile_t* out, i
  * (ssd_gnn_cache.cuh:176-186,270-280).  The reference copies num_colors entries; pass num_colors+1 to also get the
  * last colour.  Synchronises `stream`. */
 int coala_cache_color_counts(coala_cache_t* h, int32_t* dst, int32_t n_entries, void* stream);
+/* The same snapshot in two halves: _async enqueues the copy at this point of `stream` and returns without waiting; _finish (any
+ * thread) waits for that copy only and delivers dst[0 .. n_entries).  One snapshot may be pending per handle. */
+int coala_cache_color_counts_async(coala_cache_t* h, int32_t n_entries, void* stream);
+int coala_cache_color_counts_finish(coala_cache_t* h, int32_t* dst, int32_t n_entries);
 
 /* hit / miss counters since the last reset.  Replaces print_stats_kernel / print_stats (cache_kernel.cu:139-143,
  * isolated_cache.h:132-141), which print and reset.  Synchronises `stream`.  range_errors counts rejected ids. */

@@ -9,7 +9,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = os.environ.get("ROUND", "r01")
+ROUND = os.environ.get("ROUND", "r02")
 
 
 def find(tag, kind, suffix):
@@ -48,7 +48,14 @@ def main():
     line = bench_line(tag, "trace")
     steps = line["steps"] if line else 200
     if trace:
-        rows = [r for r in csv.DictReader(open(trace)) if "probe_gather_kernel" in r["Kernel_Name"]]
+        allrows = list(csv.DictReader(open(trace)))
+        per = {}
+        for r in allrows:
+            if "anonymous namespace" in r["Kernel_Name"]:
+                name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
+                per.setdefault(name, []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        summary["avg_us_rocprof_timed_region"] = {k: round(sum(v[-steps:]) / len(v[-steps:]) / 1e3, 2) for k, v in per.items()}
+        rows = [r for r in allrows if "probe_gather_kernel" in r["Kernel_Name"]]
         rows = rows[-steps:]
         durs = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
         summary["probe_gather_avg_us_rocprof_timed_region"] = round(sum(durs) / max(len(durs), 1) / 1e3, 2)
@@ -61,27 +68,38 @@ def main():
         summary["bench_value"] = line.get("value")
         summary["bench_ms_per_step"] = line.get("ms_per_step")
         summary["bench_config"] = line.get("config")
-    pmc = {}
+    # PMC passes: HBM bytes per launch of every cache kernel over the last <steps> dispatches of each (the timed region)
+    per_kernel = {}
     for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         f = find(tag, kind, "counter_collection.csv")
         if not f:
             continue
-        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
-                if "probe_gather_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter]
-        vals = vals[-steps:]
-        if vals:
-            pmc[counter] = sum(vals) / len(vals)
-    if pmc:
+        by = {}
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter or "anonymous namespace" not in r["Kernel_Name"]:
+                continue
+            name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
+            by.setdefault(name, []).append(float(r["Counter_Value"]))
+        for name, vals in by.items():
+            vals = vals[-steps:]
+            per_kernel.setdefault(name, {})[counter] = sum(vals) / len(vals)
+    pmc_tab = {}
+    for name, c in per_kernel.items():
         # counters are in KiB; FETCH_SIZE reads exactly half of a wide coalesced stream on gfx950 -> doubled
-        fetch = pmc.get("FETCH_SIZE", 0.0) * 1024.0 * 2.0
-        write = pmc.get("WRITE_SIZE", 0.0) * 1024.0
-        summary["pmc"] = {"FETCH_SIZE_KiB_per_launch_raw": pmc.get("FETCH_SIZE"), "WRITE_SIZE_KiB_per_launch_raw": pmc.get("WRITE_SIZE"),
-                          "fetch_bytes_per_launch_corrected_x2": fetch, "write_bytes_per_launch": write,
-                          "hbm_bytes_per_launch": fetch + write,
-                          "note": "last <steps> dispatches of probe_gather_kernel; FETCH_SIZE x2 (gfx950: 128-B requests tallied at 64 B)"}
-        if tag == "default":
-            with open(os.path.join(out_dir, "pmc_probe_gather.json"), "w") as f:
-                json.dump({"hbm_bytes_per_launch": int(fetch + write), "source": f"profiles/{ROUND}_{tag}_summary.json"}, f)
+        fetch = c.get("FETCH_SIZE", 0.0) * 1024.0 * 2.0
+        write = c.get("WRITE_SIZE", 0.0) * 1024.0
+        pmc_tab[name] = {"FETCH_SIZE_KiB_per_launch_raw": c.get("FETCH_SIZE"), "WRITE_SIZE_KiB_per_launch_raw": c.get("WRITE_SIZE"),
+                         "fetch_bytes_per_launch_corrected_x2": fetch, "write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write}
+    if pmc_tab:
+        summary["pmc_per_kernel"] = pmc_tab
+        summary["pmc_note"] = ("separate --pmc FETCH_SIZE / WRITE_SIZE passes, last <steps> dispatches of each kernel; FETCH_SIZE x2 (gfx950: 128-B "
+                               "requests tallied at 64 B); reads of the pinned-host cold tier do not pass the HBM counters")
+        k1 = [v for k, v in pmc_tab.items() if k.startswith("probe_gather_kernel")]
+        if k1:
+            summary["pmc"] = k1[0]
+            if tag == "default":
+                with open(os.path.join(out_dir, "pmc_probe_gather.json"), "w") as f:
+                    json.dump({"hbm_bytes_per_launch": int(k1[0]["hbm_bytes_per_launch"]), "source": f"profiles/{ROUND}_{tag}_summary.json"}, f)
     with open(os.path.join(out_dir, f"{ROUND}_{tag}_summary.json"), "w") as f:
         json.dump(summary, f, indent=1)
     # the GPU box only sends gpurun_out/ back (<= 64 MiB): mirror the small summaries there and drop the raw traces

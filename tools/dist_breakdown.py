@@ -5,6 +5,8 @@
                   (a device copy staging -> receive buffer), un-permute ALL rows
   --mode after  : the split-phase sequence -- route, probe with the own segment redirected into the output tensor, fills in
                   rounds, un-permute of the REMOTE rows only (own-shard rows never touch a staging buffer)
+  --mode bucketed : ids delivered bucketed by owner by the sampler (coala_cache_fetch_distributed_bucketed) -- no route, the own
+                  bucket gathered in place, remote rows received in place: nothing to un-permute
 Prints the time of each piece (HIP events) and the algorithmic HBM bytes of the step; under
 `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 tools/dist_breakdown.py --mode X --reps 20 --pmc`
 the per-kernel counters give the measured bytes (tools/pmc_by_kernel.py sums them)."""
@@ -20,7 +22,7 @@ import COALA_GNN_Pybind as P  # noqa: E402
 from COALA_GNN.synthetic import alloc_pinned_table  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--mode", default="both", choices=["before", "after", "both"])
+ap.add_argument("--mode", default="both", choices=["before", "after", "bucketed", "both"])
 ap.add_argument("--reps", type=int, default=200)
 ap.add_argument("--pmc", action="store_true", help="no per-piece timing loops: run the whole step --reps times (for a counter pass)")
 ap.add_argument("--rounds", type=int, default=2)
@@ -91,6 +93,12 @@ def serve_after():
         cache.serve_fill_ranges(rows_send.data_ptr(), recv_ids.data_ptr(), tot, fill[k])
 
 
+def serve_bucketed():   # the own bucket sits at its offset of `out`, in order (row_map = NULL)
+    cache.serve_probe_redirect(rows_send.data_ptr(), recv_ids.data_ptr(), tot, rdis[me], rdis[me] + rcnt[me], out.data_ptr() + sdis[me] * dim * 4, 0)
+    for k in range(K):
+        cache.serve_fill_ranges(rows_send.data_ptr(), recv_ids.data_ptr(), tot, fill[k])
+
+
 def scatter_after():
     for k in range(K):
         cache.scatter_ranges(out.data_ptr(), rows_recv.data_ptr(), mp.data_ptr(), land[k])
@@ -114,9 +122,10 @@ probe_b = tot * (8 + 256)
 modes = {"before": [("route", route, 0), ("serve -> staging", serve_before, probe_b + 2 * tot * row),
                     ("self segment copy", self_copy, 2 * scnt[me] * row), ("un-permute all rows", scatter_before, 2 * n * row + 8 * n)],
          "after": [("route", route, 0), ("probe+fills (own shard -> out)", serve_after, probe_b + 2 * tot * row + 8 * scnt[me]),
-                   ("un-permute remote rows", scatter_after, 2 * (n - scnt[me]) * row + 8 * (n - scnt[me]))]}
+                   ("un-permute remote rows", scatter_after, 2 * (n - scnt[me]) * row + 8 * (n - scnt[me]))],
+         "bucketed": [("probe+fills (own bucket in place)", serve_bucketed, probe_b + 2 * tot * row)]}
 print(f"G={G} rank {me}: batch {n} rows x {row} B, own bucket {scnt[me]} rows, owner batch {tot} rows (all hits), rounds {K}")
-for mode in (["before", "after"] if args.mode == "both" else [args.mode]):
+for mode in (["before", "after", "bucketed"] if args.mode == "both" else [args.mode]):
     if args.pmc:
         for _ in range(args.reps):
             for _, fn, _ in modes[mode]:
@@ -129,7 +138,7 @@ for mode in (["before", "after"] if args.mode == "both" else [args.mode]):
         us = timeit(fn, args.reps)
         total_us += us
         total_b += nbytes
-        print(f"  {mode:6s} {name:32s} {us:8.2f} us   {nbytes / 1e6:8.2f} MB algorithmic HBM traffic" + (f"   {nbytes / us / 1e3:7.1f} GB/s" if nbytes else ""))
-    print(f"  {mode:6s} {'TOTAL (device kernels, one rank)':32s} {total_us:8.2f} us   {total_b / 1e6:8.2f} MB per step")
+        print(f"  {mode:8s} {name:34s} {us:8.2f} us   {nbytes / 1e6:8.2f} MB algorithmic HBM traffic" + (f"   {nbytes / us / 1e3:7.1f} GB/s" if nbytes else ""))
+    print(f"  {mode:8s} {'TOTAL (device kernels, one rank)':34s} {total_us:8.2f} us   {total_b / 1e6:8.2f} MB per step")
 hit, miss, _ = cache.stats()
 assert miss == 0, (hit, miss)

@@ -7,7 +7,7 @@ OUT=$R/gpurun_out/r02_dist_step_kernels.txt
 export TMPDIR=/tmp
 cd /tmp
 python3 $R/tools/dist_breakdown.py --mode both > $OUT 2>&1
-for mode in before after; do
+for mode in before after bucketed; do
   for c in FETCH_SIZE WRITE_SIZE; do
     d=$R/gpurun_out/prof_dist_${mode}_${c}
     rm -rf $d

@@ -5,7 +5,7 @@
 # tools/summarize_profiles.py then writes the tracked summaries into profiles/.
 set -e
 R=${GRAFT_REPO_ROOT:-$PWD}
-ARGS="${BENCH_ARGS:---no-cpu-baseline --no-allhit --epoch-steps 0}"   # the timed region only: the extra legs would add launches of the same kernels after it
+ARGS="${BENCH_ARGS:---no-cpu-baseline --no-allhit --epoch-steps 0 --no-fanout-leg --no-color-affinity-leg}"   # the timed region only: the extra legs would add launches of the same kernels after it
 TAG="${TAG:-default}"
 export TMPDIR=/tmp
 cd /tmp

@@ -266,9 +266,12 @@ class NativeExchange(object):
         self._capi.check(self._lib.coala_comm_profile(self._h, -1, None, 1))
 
     def fetch(self, ops, out_ptr, idx_ptr, n, max_index=0):
-        from COALA_GNN_Pybind import current_stream
-        self._capi.check(self._lib.coala_cache_fetch_distributed(ops._h, self._h, int(out_ptr) or None, int(idx_ptr) or None, int(n),
-                                                                  current_stream()))
+        from COALA_GNN_Pybind import current_stream, native
+        if native is not None:   # compiled binding: no ctypes marshalling on the per-step path
+            native.cache_fetch_distributed(ops._h.value or 0, self._h.value or 0, int(out_ptr), int(idx_ptr), int(n), current_stream())
+        else:
+            self._capi.check(self._lib.coala_cache_fetch_distributed(ops._h, self._h, int(out_ptr) or None, int(idx_ptr) or None, int(n),
+                                                                      current_stream()))
         send = (self._C.c_int64 * self.world)()
         recv = (self._C.c_int64 * self.world)()
         self._lib.coala_comm_last_counts(self._h, send, recv)
@@ -276,9 +279,13 @@ class NativeExchange(object):
 
     def fetch_bucketed(self, ops, out_ptr, idx_ptr, n, counts_ptr):
         """idx already bucketed by owner (NeighborSampler(bucket_by_owner=G)): no routing pass, rows received in place."""
-        from COALA_GNN_Pybind import current_stream
-        self._capi.check(self._lib.coala_cache_fetch_distributed_bucketed(ops._h, self._h, int(out_ptr) or None, int(idx_ptr) or None, int(n),
-                                                                           int(counts_ptr), current_stream()))
+        from COALA_GNN_Pybind import current_stream, native
+        if native is not None:
+            native.cache_fetch_distributed_bucketed(ops._h.value or 0, self._h.value or 0, int(out_ptr), int(idx_ptr), int(n), int(counts_ptr),
+                                                    current_stream())
+        else:
+            self._capi.check(self._lib.coala_cache_fetch_distributed_bucketed(ops._h, self._h, int(out_ptr) or None, int(idx_ptr) or None, int(n),
+                                                                               int(counts_ptr), current_stream()))
         send = (self._C.c_int64 * self.world)()
         recv = (self._C.c_int64 * self.world)()
         self._lib.coala_comm_last_counts(self._h, send, recv)

@@ -20,9 +20,20 @@ from ._capi import CacheConfig, CacheGeometry, CacheProfile, check
 
 _lib = _capi.load()
 
+# The compiled binding (csrc/coala_pybind.cpp -> _coala_pybind*.so, built by build.py): the reference's class surface as a
+# pybind11 module over the same C ABI.  When present, the per-step calls below go through it (GIL released, no ctypes
+# marshalling) and the compiled classes are reachable as COALA_GNN_Pybind.native.<Class>; when absent (not built), everything
+# runs through the ctypes table.  Loaded AFTER _capi.load(): torch first, then one libcoala_hip.so for both.
+try:
+    from . import _coala_pybind as native
+    if native.abi_version() != _lib.coala_abi_version():
+        native = None
+except ImportError:
+    native = None
+
 __all__ = [
     "SharedUVAManager", "SSD_GNN_SSD_Controllers", "SSD_GNN_NVSHMEM_Cache", "Isolated_Cache", "Node_distributor_pybind",
-    "NVSHMEM_Manager", "Graph_Coloring", "current_stream", "set_stream_provider",
+    "NVSHMEM_Manager", "Graph_Coloring", "current_stream", "set_stream_provider", "native",
 ]
 
 
@@ -261,10 +272,16 @@ class _CacheBase:
 
     # primitives shared by both cache classes -------------------------------------------------------------------
     def _read(self, out_ptr, idx_ptr, n):
-        check(_lib.coala_cache_read_feature(self._h, int(out_ptr), int(idx_ptr), int(n), current_stream()))
+        if native is not None:
+            native.cache_read_feature(self._h.value or 0, int(out_ptr), int(idx_ptr), int(n), current_stream())
+        else:
+            check(_lib.coala_cache_read_feature(self._h, int(out_ptr), int(idx_ptr), int(n), current_stream()))
 
     def _serve(self, out_ptr, ids_ptr, n):
-        check(_lib.coala_cache_serve(self._h, int(out_ptr), int(ids_ptr), int(n), current_stream()))
+        if native is not None:
+            native.cache_serve(self._h.value or 0, int(out_ptr), int(ids_ptr), int(n), current_stream())
+        else:
+            check(_lib.coala_cache_serve(self._h, int(out_ptr), int(ids_ptr), int(n), current_stream()))
 
     def serve_probe(self, out_ptr, ids_ptr, n):
         """First phase of a split serve: classify the whole batch, copy the hits (coala_cache_serve_probe)."""

@@ -6,6 +6,7 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("coala_cache.hip", "coala_sampler.hip", "coala_host.cpp", "coala_coloring.cpp", "coala_comm.cpp")]
+PYBIND_SRC = os.path.join(_HERE, "csrc", "coala_pybind.cpp")
 HEADERS = [os.path.join(_ROOT, "include", "coala_hip.h"), os.path.join(_HERE, "csrc", "coala_internal.h")]
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libcoala_hip.so")
@@ -52,5 +53,32 @@ def build_lib(force=False, verbose=False, dev=False):
     return out
 
 
+def pybind_path():
+    import sysconfig
+    return os.path.join(_HERE, "COALA_GNN_Pybind", "_coala_pybind" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+
+
+def build_pybind(force=False, verbose=False):
+    """Compile the pybind11 module COALA_GNN_Pybind/_coala_pybind (host C++ only, g++) against libcoala_hip.so -- the compiled
+    counterpart of the reference's COALA_GNN_Pybind.cu.  Needs the library built first."""
+    import pybind11
+    import sysconfig
+    out = pybind_path()
+    deps = [PYBIND_SRC] + HEADERS
+    if not force and os.path.exists(out) and all(os.path.getmtime(p) <= os.path.getmtime(out) for p in deps):
+        return out
+    build_lib()
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-I", pybind11.get_include(),
+           "-I", sysconfig.get_paths()["include"], PYBIND_SRC, "-o", out + ".tmp",
+           "-L", LIB_DIR, "-lcoala_hip", "-Wl,-rpath,$ORIGIN/../lib"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(out + ".tmp", out)
+    return out
+
+
 if __name__ == "__main__":
     print(build_lib(force="--force" in sys.argv, verbose=True, dev="--dev" in sys.argv))
+    if "--dev" not in sys.argv:
+        print(build_pybind(force="--force" in sys.argv, verbose=True))

@@ -30,5 +30,6 @@ def hiplib():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     mod.build_lib()
+    mod.build_pybind()
     import COALA_GNN_Pybind
     return COALA_GNN_Pybind

@@ -218,6 +218,75 @@ class AllToAllExchange(object):
         self.send_requests(ops, idx_ptr, n, 0, max_index)
         self.read_feature(ops, out_ptr, 0, max_index)
 
+    def fetch_bucketed(self, ops, out_ptr, idx_ptr, n, counts_ptr):
+        """idx already bucketed by owner (NeighborSampler(bucket_by_owner=G)), counts on the device: no routing pass, every
+        peer's rows are received straight into the output tensor, nothing to un-permute (mirror of
+        coala_cache_fetch_distributed_bucketed)."""
+        n, G, me, dim = int(n), self.world, self.rank, self.dim
+        self.counts.copy_(_tensor_view(counts_ptr, G, torch.int64, self.counts))
+        self._a2a(self.recv_counts, self.counts)
+        self._both_dev[0].copy_(self.counts)
+        self._both_dev[1].copy_(self.recv_counts)
+        self._both_host.copy_(self._both_dev, non_blocking=True)
+        if self._both_dev.is_cuda:
+            torch.cuda.current_stream().synchronize()
+        send_c, recv_c = self._both_host[0].tolist(), self._both_host[1].tolist()
+        if sum(send_c) != n:
+            raise RuntimeError(f"the bucket counts sum to {sum(send_c)} for a batch of {n} ids")
+        self.last_send_counts, self.last_recv_counts = send_c, recv_c
+        total_recv = int(sum(recv_c))
+        sdis = [sum(send_c[:p]) for p in range(G)]
+        rdis = [sum(recv_c[:p]) for p in range(G)]
+        node = _tensor_view(idx_ptr, n, torch.int64, self.counts)
+        out = _tensor_view(out_ptr, n * dim, torch.float32, self.counts).view(-1, dim) if n else None
+        recv_ids = self._buf("recv_ids", total_recv, torch.int64)
+        self._a2a(recv_ids[:total_recv], node[:n], recv_c, send_c)
+        rows_send = self._buf("rows_send", total_recv * dim, torch.float32)[: max(total_recv, 1) * dim].view(-1, dim)
+        K = 1 if G == 1 else self.rounds
+        if total_recv:
+            ops.serve_probe_redirect(rows_send.data_ptr(), recv_ids.data_ptr(), total_recv, rdis[me], rdis[me] + recv_c[me],
+                                     int(out_ptr) + sdis[me] * dim * 4, 0)
+        fill = _round_slices(recv_c, rdis, K, me)
+        land = _round_slices(send_c, sdis, K, me)
+        cur = torch.cuda.current_stream() if rows_send.is_cuda else None
+        done = []
+        for k in range(K):
+            if total_recv:
+                rng = [r for r in fill[k] if r[1] > r[0]]
+                if k == K - 1 and recv_c[me]:
+                    rng.append((rdis[me], rdis[me] + recv_c[me]))
+                ops.serve_fill_ranges(rows_send.data_ptr(), recv_ids.data_ptr(), total_recv, rng)
+            if G == 1:
+                continue
+            dst = out if out is not None else rows_send[:0]   # a rank with an empty batch still takes part in the collective
+            if self._side is not None:
+                ev = torch.cuda.Event()
+                ev.record(cur)
+                self._side.wait_event(ev)
+                with torch.cuda.stream(self._side):
+                    self._a2a_slices(dst, land[k], rows_send, fill[k])
+                    e2 = torch.cuda.Event()
+                    e2.record()
+                done.append(e2)
+            else:
+                self._a2a_slices(dst, land[k], rows_send, fill[k])
+        for e2 in done:
+            cur.wait_event(e2)
+
+
+def _tensor_view(ptr, numel, dtype, like):
+    """A tensor over caller-owned memory at `ptr` on the device of `like` (CPU tensors for the gloo tests, HBM otherwise)."""
+    if numel == 0:
+        return torch.empty(0, dtype=dtype, device=like.device)
+    if like.is_cuda:
+        from .Shared_Tensor import tensor_from_pointer
+        return tensor_from_pointer(int(ptr), (int(numel),), dtype, like.device)
+    import ctypes
+    import numpy as np
+    npdt = np.dtype(torch.empty(0, dtype=dtype).numpy().dtype)
+    buf = (ctypes.c_char * (int(numel) * npdt.itemsize)).from_address(int(ptr))
+    return torch.from_numpy(np.frombuffer(buf, dtype=npdt))
+
 
 class NativeExchange(object):
     """The same exchange as ONE native call (coala_cache_fetch_distributed: route, counts, ids, probe with the own shard

@@ -113,6 +113,20 @@ def mode_exchange():
         assert (mine.hit_cnt, mine.miss_cnt) == (ref[r].hit_cnt, ref[r].miss_cnt), f"rank {r}: owner counters differ from the collective oracle"
         assert np.array_equal(mine.keys(), ref[r].keys())
         assert sum(ex.last_send_counts) == len(idx) and ex.last_send_counts == [int((lists[r] % G == g).sum()) for g in range(G)]
+    # the bucketed fast path: ids pre-bucketed by owner (what the sampler delivers), counts on the "device"
+    for step in range(5, 8):
+        rng = np.random.default_rng(100 + step)
+        raw = [rng.choice(rows, size=int(rng.integers(0, 1500)) if step != 6 or g else 0, replace=False).astype(np.int64) for g in range(G)]
+        lists = [np.concatenate([x[x % G == o] for o in range(G)]) if len(x) else x for x in raw]   # stable partition
+        idx = torch.from_numpy(lists[r].copy())
+        cnt = torch.tensor([int((lists[r] % G == o).sum()) for o in range(G)], dtype=torch.int64)
+        out = torch.full((max(len(idx), 1), dim), -1.0)
+        ex.rounds = 1 + step % 3
+        ex.fetch_bucketed(ops, out.data_ptr(), idx.data_ptr(), len(idx), cnt.data_ptr())
+        assert ops._open is None
+        O.dist_fetch(ref, lists)
+        assert np.array_equal(out.numpy()[: len(idx)], feat[lists[r]]), f"rank {r} step {step}: bucketed rows differ"
+        assert (mine.hit_cnt, mine.miss_cnt) == (ref[r].hit_cnt, ref[r].miss_cnt) and np.array_equal(mine.keys(), ref[r].keys())
     comm.destroy_process_group()
 
 

@@ -329,6 +329,48 @@ def test_native_bucketed_fetch_from_sampler_output(hiplib, oracle, G, dim, round
         t.close()
 
 
+def test_fill_and_scatter_over_many_ranges(hiplib, oracle):
+    """More ranges than one kernel launch carries (64): serve_fill_ranges / scatter_ranges split them over several launches; rows,
+    counters and table still equal one serve / one scatter."""
+    import torch
+    P = hiplib
+    dim, num_rows, n = 128, 30000, 6000
+    feat = oracle.make_features(num_rows, dim, seed=5)
+    table = PinnedTable(P, feat)
+    ctrl = P.SSD_GNN_SSD_Controllers(1, 512, 1024, 0, 0, dim, True)
+    a = P.SSD_GNN_NVSHMEM_Cache(ctrl, None, 0, 1, 1, table.device_ptr, num_rows=num_rows, rank=0)
+    b = P.SSD_GNN_NVSHMEM_Cache(ctrl, None, 0, 1, 1, table.device_ptr, num_rows=num_rows, rank=0)
+    rng = np.random.default_rng(9)
+    for step in range(3):
+        ids = rng.choice(num_rows, size=n, replace=False).astype(np.int64)
+        d_ids = torch.from_numpy(ids).cuda()
+        out_a = torch.full((n, dim), -1.0, device="cuda")
+        out_b = torch.full((n, dim), -1.0, device="cuda")
+        a.serve(out_a.data_ptr(), d_ids.data_ptr(), n)
+        cuts = sorted({0, n, *(int(c) for c in rng.integers(1, n, size=170))})
+        ranges = list(zip(cuts[:-1], cuts[1:]))
+        assert len(ranges) > 128
+        rng.shuffle(ranges)
+        b.serve_probe(out_b.data_ptr(), d_ids.data_ptr(), n)
+        b.serve_fill_ranges(out_b.data_ptr(), d_ids.data_ptr(), n, ranges[:100])
+        b.serve_fill_ranges(out_b.data_ptr(), d_ids.data_ptr(), n, ranges[100:])
+        torch.cuda.synchronize()
+        assert torch.equal(out_a, out_b) and out_b.cpu().numpy().tobytes() == feat[ids].tobytes()
+        assert a.stats() == b.stats()
+        for x, y in zip(a.dump(), b.dump()):
+            assert np.array_equal(x, y)
+        # un-permute through 171 ranges == one scatter
+        perm = torch.randperm(n, device="cuda")
+        dst1 = torch.zeros((n, dim), device="cuda")
+        dst2 = torch.zeros((n, dim), device="cuda")
+        a.scatter(dst1.data_ptr(), out_a.data_ptr(), perm.data_ptr(), n)
+        a.scatter_ranges(dst2.data_ptr(), out_a.data_ptr(), perm.data_ptr(), ranges)
+        torch.cuda.synchronize()
+        assert torch.equal(dst1, dst2) and torch.equal(dst1[perm], out_a)
+    a.close(); b.close()
+    table.close()
+
+
 def test_open_batch_is_guarded(hiplib, oracle):
     """a probe while a probed batch still waits for fills, a fill that overlaps an earlier one, or a fill for another
     batch size must be refused (stale verdicts would corrupt the next batch); serve_abort drops the open batch."""

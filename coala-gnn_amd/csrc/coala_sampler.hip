@@ -549,7 +549,7 @@ int coala_sampler_wait(coala_sampler_t* s, int64_t ticket, int64_t* n_src_host, 
 int coala_sampler_sample(coala_sampler_t* s, const int64_t* seeds, int64_t n_seeds, const int32_t* fanouts, int n_layers,
                          uint64_t seed, uint64_t step, int64_t* const* src_nodes_out, int32_t* const* nbr_local_out,
                          int64_t* n_src_host, const coala_sampler_bucketing_t* bucketing, int64_t* ticket_out, void* stream) {
-    if (!s || !seeds || !fanouts || !src_nodes_out || !nbr_local_out) return fail(COALA_EINVAL, "null argument");
+    if (!s || (!seeds && n_seeds > 0) || !fanouts || !src_nodes_out || !nbr_local_out) return fail(COALA_EINVAL, "null argument");
     if (n_layers < 1 || n_layers > COALA_SAMPLER_MAX_LAYERS) return fail(COALA_EINVAL, "n_layers must be 1..%d", COALA_SAMPLER_MAX_LAYERS);
     if (n_seeds < 0 || n_seeds > 0x7FFFFFFF) return fail(COALA_EINVAL, "bad n_seeds");
     const int n_parts = bucketing ? bucketing->n_parts : 0;

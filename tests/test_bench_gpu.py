@@ -87,3 +87,16 @@ def test_color_affinity_probe_two_domains():
     assert d["num_colors"] > 10
     h = d["hit_ratio_all_domains"]
     assert h["node_color"] > h["baseline"] - 0.01, h     # on a graph with communities affinity routing must not lose
+
+
+def test_backend_compare_probe_logical_ranks():
+    """examples/Cache_compare_script.sh on one GPU: isolated caches vs the owner-partitioned cache with 3 logical ranks (host threads, the
+    fused native fetch over the in-process transport).  Both modes deliver the table's rows bit-exact; sharing one sharded cache can
+    only raise the aggregate hit ratio at equal per-rank capacity."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "backend_compare_probe.py"), "--ranks", "3", "--rows", "300000", "--dim", "256",
+                          "--cache-mb", "16", "--batch", "256", "--steps", "120", "--measure-from", "60"], capture_output=True, text=True, timeout=600)
+    d = _line(out)
+    for mode in ("isolated", "partitioned"):
+        assert len(d[mode]["per_rank"]) == 3 and all(r["rows_checked_bit_exact_steps"] >= 1 for r in d[mode]["per_rank"])
+        assert 0 < d[mode]["hit_ratio_all_ranks"] < 1
+    assert d["partitioned"]["hit_ratio_all_ranks"] > d["isolated"]["hit_ratio_all_ranks"]

@@ -48,6 +48,7 @@ def main():
     indptr, indices = powerlaw_csc(args.rows, 12.0, seed=0, device="cuda")
     train = torch.randperm(int(0.6 * args.rows), generator=torch.Generator().manual_seed(0))
     ctrl = P.SSD_GNN_SSD_Controllers(1, dim * 4, 1024, 0, 0, dim, True)
+    spe = len(train) // (G * args.batch)          # steps per epoch of the data-parallel run
     out = {}
     for mode in ("isolated", "partitioned"):
         part = mode == "partitioned"
@@ -77,7 +78,7 @@ def main():
                             caches[r].stats(reset=True)
                             bar.wait()
                             t0 = time.perf_counter()
-                        lo = (step * G + r) * args.batch          # rank r takes the r-th batch of the global batch
+                        lo = ((step % spe) * G + r) * args.batch  # rank r takes the r-th batch of the global batch
                         ids, _, blocks = samplers[r].sample(graphs[r], train[lo: lo + args.batch].cuda(), step=step)
                         n = ids.numel()
                         feat = torch.empty((n, dim), dtype=torch.float32, device="cuda")

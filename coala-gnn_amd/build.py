@@ -41,7 +41,10 @@ def build_lib(force=False, verbose=False, dev=False):
     if not force and not dev and not needs_build():
         return out
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", os.path.join(_ROOT, "include")]
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", os.path.join(_ROOT, "include"),
+           # leading scalar kernel arguments arrive in SGPRs (gfx940+ kernarg preload): K1's first id load no longer waits for a
+           # kernarg fetch (tools/k1_insitu.py: -0.15 us per launch)
+           "-mllvm", "-amdgpu-kernarg-preload-count=16"]
     if dev:
         cmd.append("-DCOALA_DEV_KNOBS")
         cmd += os.environ.get("COALA_EXTRA_HIPCC_FLAGS", "").split()

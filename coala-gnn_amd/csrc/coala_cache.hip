@@ -158,7 +158,10 @@ constexpr int kK1MaxWaves = kK1Waves;
 
 template <typename V> __device__ __forceinline__ V nt_load(const V* p) { return __builtin_nontemporal_load(p); }
 template <typename V> __device__ __forceinline__ void nt_store(V v, V* p) { __builtin_nontemporal_store(v, p); }
-// K1's row moves (development builds can flip them with -DK1_PLAIN_LOADS / -DK1_PLAIN_STORES: tools/k1_insitu.py)
+// K1's row moves: nontemporal loads of the lines (touched once per batch: keeps them from displacing the tag sets; plain loads are
+// 0.5 us faster at 32 % hits but 3 us slower on an all-hit batch), plain stores of the output rows (0.3-0.4 us faster than
+// nontemporal ones in situ and on the all-hit batch, and the consumer reads them next).  Development builds can flip either
+// with -DK1_PLAIN_LOADS / -DK1_NT_STORES (tools/k1_insitu.py).
 template <typename V> __device__ __forceinline__ V k1_load(const V* p) {
 #ifdef K1_PLAIN_LOADS
     return *p;
@@ -167,17 +170,17 @@ template <typename V> __device__ __forceinline__ V k1_load(const V* p) {
 #endif
 }
 template <typename V> __device__ __forceinline__ void k1_store(V v, V* p) {
-#ifdef K1_PLAIN_STORES
-    *p = v;
-#else
+#ifdef K1_NT_STORES
     __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
 #endif
 }
 
 template <int CD, int VEC, int NP = 4, bool FULL = false, int NOMISS = 0 /* development only: 1 = no miss bookkeeping */, bool REDIR = false>
 __global__ __launch_bounds__(64 * kK1MaxWaves, K1_MIN_WAVES) void probe_gather_kernel(const int64_t* __restrict__ idx, float* __restrict__ out,
                                                                     int64_t n, uint32_t gen, uint32_t n_blocks, CacheDev c, Redirect rd) {
-    // Argument order and the explicit block count are deliberate: with kernarg preloading (build.py: -amdgpu-kernarg-preload-count)
+    // Argument order and the explicit block count are deliberate: with kernarg preloading (build.py: -mllvm -amdgpu-kernarg-preload-count=16)
     // the leading scalar arguments arrive in SGPRs, and with the compile-time block shape the first id load needs nothing from
     // the kernarg segment -- the s_loads of the CacheDev fields then overlap that load instead of preceding it.
     // FULL: dim == cache_dim, every lane of a row group moves data -> no per-lane bounds predicate around the row moves

@@ -13,6 +13,7 @@ Per minibatch the exchange is: route (stable bucketing on the GPU) -> all-to-all
 all-to-all-v of rows -> un-permute.  The reference instead moves full-capacity id buffers (:159-163) and G(G-1) serial
 send/recv pairs (:194-203).
 """
+import contextlib
 import time
 
 import torch
@@ -249,6 +250,8 @@ class AllToAllExchange(object):
         fill = _round_slices(recv_c, rdis, K, me)
         land = _round_slices(send_c, sdis, K, me)
         cur = torch.cuda.current_stream() if rows_send.is_cuda else None
+        timed = self.profile and rows_send.is_cuda and G > 1
+        ev_t = None
         done = []
         for k in range(K):
             if total_recv:
@@ -263,13 +266,21 @@ class AllToAllExchange(object):
                 ev = torch.cuda.Event()
                 ev.record(cur)
                 self._side.wait_event(ev)
-                with torch.cuda.stream(self._side):
-                    self._a2a_slices(dst, land[k], rows_send, fill[k])
+            with torch.cuda.stream(self._side) if self._side is not None else contextlib.nullcontext():
+                if timed and k == 0:
+                    ev_t = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    ev_t[0].record()
+                self._a2a_slices(dst, land[k], rows_send, fill[k])
+                if timed and k == K - 1:
+                    ev_t[1].record()
+                if self._side is not None:
                     e2 = torch.cuda.Event()
                     e2.record()
-                done.append(e2)
-            else:
-                self._a2a_slices(dst, land[k], rows_send, fill[k])
+                    done.append(e2)
+        if timed and ev_t is not None:
+            self._row_events.append(ev_t)
+            self.rows_a2a_calls += 1
+            self.remote_rows_in += n - int(send_c[me])
         for e2 in done:
             cur.wait_event(e2)
 

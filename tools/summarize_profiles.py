@@ -10,6 +10,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ROUND = os.environ.get("ROUND", "r02")
+OUR = ("probe_gather_kernel", "miss_fill_kernel", "scatter_rows_kernel", "route_", "sample_insert_kernel", "scan_assign_kernel", "relabel_clear_kernel",
+       "bucket_", "mean_aggregate")  # the product's kernels (torch has kernels in anonymous namespaces too)
 
 
 def find(tag, kind, suffix):
@@ -53,7 +55,8 @@ def main():
         for r in allrows:
             if "anonymous namespace" in r["Kernel_Name"]:
                 name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
-                per.setdefault(name, []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+                if name.startswith(OUR):
+                    per.setdefault(name, []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
         summary["avg_us_rocprof_timed_region"] = {k: round(sum(v[-steps:]) / len(v[-steps:]) / 1e3, 2) for k, v in per.items()}
         rows = [r for r in allrows if "probe_gather_kernel" in r["Kernel_Name"]]
         rows = rows[-steps:]
@@ -79,7 +82,8 @@ def main():
             if r["Counter_Name"] != counter or "anonymous namespace" not in r["Kernel_Name"]:
                 continue
             name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
-            by.setdefault(name, []).append(float(r["Counter_Value"]))
+            if name.startswith(OUR):
+                by.setdefault(name, []).append(float(r["Counter_Value"]))
         for name, vals in by.items():
             vals = vals[-steps:]
             per_kernel.setdefault(name, {})[counter] = sum(vals) / len(vals)

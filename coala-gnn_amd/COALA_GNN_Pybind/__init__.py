@@ -24,12 +24,16 @@ _lib = _capi.load()
 # pybind11 module over the same C ABI.  When present, the per-step calls below go through it (GIL released, no ctypes
 # marshalling) and the compiled classes are reachable as COALA_GNN_Pybind.native.<Class>; when absent (not built), everything
 # runs through the ctypes table.  Loaded AFTER _capi.load(): torch first, then one libcoala_hip.so for both.
-try:
-    from . import _coala_pybind as native
-    if native.abi_version() != _lib.coala_abi_version():
+native = None
+if os.path.realpath(_capi.LIB_PATH) == os.path.realpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), os.pardir, "lib", "libcoala_hip.so")):
+    # (the compiled module is linked against THAT library: with COALA_HIP_LIB pointing elsewhere -- the development build --
+    # handles created by one library must not be driven by the other)
+    try:
+        from . import _coala_pybind as native
+        if native.abi_version() != _lib.coala_abi_version():
+            native = None
+    except ImportError:
         native = None
-except ImportError:
-    native = None
 
 __all__ = [
     "SharedUVAManager", "SSD_GNN_SSD_Controllers", "SSD_GNN_NVSHMEM_Cache", "Isolated_Cache", "Node_distributor_pybind",

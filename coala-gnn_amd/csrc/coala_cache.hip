@@ -706,8 +706,9 @@ struct coala_cache {
     Redirect open_redirect{0, 0, nullptr, nullptr};       // the open batch's redirect (set by the probe, reused by its fills)
     int k2_tile_rows = 0;                 // rows per verdict tile of K2: 64 for a host cold tier, 0 = one chunk (COALA_K2_TILE_ROWS)
     int k1_passes = 4;                    // rows(-pairs) in flight per wave in K1 (tunable: COALA_K1_PASSES = 2 | 4)
-    int k1_grid_cap = 8192;               // K1 blocks: one chunk per wave up to 65,536 rows (measured in situ, 28.5 k rows at 32 % hits: 2048 -> 22.3 us,
-                                          // 4096 -> 20.7, 8192 -> 20.6; all-hit 36,864 rows: 53.8 / 53.1 / 51.4 us; tools/k1_insitu.py)
+    int k1_grid_cap = 16384;              // K1 blocks: one chunk per wave up to 131,072 rows.  Measured (tools/k1_insitu.py, tools/k1_bench): 28.5 k rows at 32 %
+                                          // hits in situ: 2048 blocks -> 22.3 us, 4096 -> 20.7, 8192 -> 20.6; all-hit 36,864 rows: 53.8 / 53.1 / 51.4 us;
+                                          // all-hit 123,904 rows: 192.5 / 192.3 / 190.1 / 185.3 us at 2048 / 4096 / 8192 / 16384; 1.08 M x 512 B: 232 -> 227 us
     int k1_waves = kK1Waves;              // K1 waves per block
     uint64_t rows_total = 0;              // rows submitted since the last stats reset (hits = rows - misses - rejected)
     uint64_t cum_hit = 0, cum_miss = 0;   // totals folded in whenever coala_cache_stats resets the device counters
@@ -1061,11 +1062,7 @@ static int read_feature_impl(coala_cache_t* h, float* out, const int64_t* idx, i
         if (phases & kPhaseProbe) {
             ProfScope ps(h, s, 0, (uint64_t)n);
             const bool full = (VEC == 4) && ((int)d.dim == CD);
-            // one chunk per wave while the batch is small (the launch is then one pipeline fill + drain: more waves = more bytes in
-            // flight from the start); past 2 x cap chunks the waves run a steady-state software pipeline and fewer, longer-lived ones
-            // win (123,904 all-hit rows: 187 us with 2048 blocks against 201 us with 8192)
-            const int cap = chunks <= 2 * (int64_t)h->k1_grid_cap * h->k1_waves ? h->k1_grid_cap : 2048;
-            const dim3 grid(grid_for(chunks, h->k1_waves, cap)), block(64 * h->k1_waves);
+            const dim3 grid(grid_for(chunks, h->k1_waves, h->k1_grid_cap)), block(64 * h->k1_waves);
             if (redir) {
                 hipLaunchKernelGGL((probe_gather_kernel<CD, VEC, 4, false, 0, true>), grid, block, 0, s, idx, out, n, gen, grid.x, d, rd);
             } else if (h->k1_passes == 2) {

@@ -225,7 +225,7 @@ int main(int argc, char** argv) {
             else if (dim == 128 && np == 2) hipLaunchKernelGGL((probe_gather_kernel<128, 4, 2>), dim3(grid), dim3(block), 0, s, d_ids, out, n, fake_gen, (uint32_t)grid, h->d, Redirect{0, 0, nullptr, nullptr});
         }});
     };
-    add_prod(2048, 128, 4); add_prod(2048, 128, 5); add_prod(8192, 128, 5); add_prod(2048, 128, 6); add_prod(8192, 128, 6);
+    add_prod(2048, 128, 4); add_prod(2048, 128, 5); add_prod(4096, 128, 5); add_prod(8192, 128, 5); add_prod(16384, 128, 5); add_prod(2048, 128, 6); add_prod(8192, 128, 6);
     if (hit_pct == 100) {
         if (dim == 1024) {
             auto add_v2 = [&](const char* nm, auto kern, int grid, int block) {

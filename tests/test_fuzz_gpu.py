@@ -1,80 +1,39 @@
 """Seeded randomized sweep of the cache path against the oracle: random dims (vector and scalar paths, dim < cache_dim),
 cache sizes (power-of-two and odd set counts), owner-partition degrees, batch shapes with duplicates / rejected ids / empty
-batches, with and without colour tracking.  Bit-exact rows, counters, tag table and colour counters after every batch."""
-import numpy as np
+batches, with and without colour tracking, whole serves and split serves (random redirect slice + row map, fills over random
+range sets in random order).  Bit-exact rows, counters, tag table, cursors and colour counters after every batch."""
+import importlib.util
+import os
+import subprocess
+import sys
+
 import pytest
 
-from _util import ColorFiles, PinnedTable
+import _fuzz_body
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-
-# the fill kernel's launch shape is a tunable of the handle (read at creation): sweep it with the seeds -- the default for a
-# host cold tier (64-row verdict tiles), one chunk per step as behind an HBM tier, and an odd narrow grid with 16-row tiles
-KNOBS = {1: {}, 2: {"COALA_K2_TILE_ROWS": "0"}, 3: {"COALA_K2_TILE_ROWS": "16", "COALA_K2_GRID": "3"},
-         4: {"COALA_K2_TILE_ROWS": "64", "COALA_K2_GRID": "1", "COALA_K1_GRID": "5"}}
+# the launch shape of the kernels is a tunable of the DEVELOPMENT library only (read at handle creation): the default for a host
+# cold tier (64-row verdict tiles), one chunk per step as behind an HBM tier, an odd narrow grid with 16-row tiles, one-block grids
+KNOBS = {2: {"COALA_K2_TILE_ROWS": "0"}, 3: {"COALA_K2_TILE_ROWS": "16", "COALA_K2_GRID": "3"},
+         4: {"COALA_K2_TILE_ROWS": "64", "COALA_K2_GRID": "1", "COALA_K1_GRID": "5"}, 5: {"COALA_K1_WAVES": "4", "COALA_K1_PASSES": "2"}}
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])
-def test_randomized_configs_match_oracle(hiplib, oracle, tmp_path, seed, monkeypatch):
-    import torch
-    P = hiplib
-    for k, v in KNOBS[seed].items():
-        monkeypatch.setenv(k, v)
-    rng = np.random.default_rng(1000 + seed)
-    for case in range(12):
-        dim = int(rng.choice([1, 3, 4, 17, 64, 100, 128, 129, 200, 256, 300, 511, 512, 640, 1000, 1024]))
-        cache_mb = int(rng.choice([1, 2, 3, 5]))
-        n_gpus = int(rng.choice([1, 1, 2, 3, 8]))
-        distributed = n_gpus > 1
-        num_rows = int(rng.integers(500, 9000))
-        with_color = bool(rng.integers(0, 2))
-        num_colors = int(rng.integers(1, 30))
-        feat = oracle.make_features(num_rows, dim, seed=case + 10 * seed)
-        table = PinnedTable(P, feat)
-        color = rng.integers(0, num_colors + 1, size=num_rows).astype(np.int64) if with_color else None
-        nd = None
-        if with_color:
-            d = tmp_path / f"s{seed}c{case}"
-            d.mkdir()
-            files = ColorFiles(d, color, np.zeros((num_colors, 2), np.int64), np.zeros((num_colors, 2)))
-            items = np.zeros(2, dtype=np.int64)
-            nd = P.Node_distributor_pybind(items.ctypes.data, 0, 1, 1, 1, files.color_file, files.topk_file, files.score_file)
-        ctrl = P.SSD_GNN_SSD_Controllers(1, 4096, 1024, 0, 0, dim, True)
-        cls = P.SSD_GNN_NVSHMEM_Cache if distributed else P.Isolated_Cache
-        cache = cls(ctrl, nd, 0, n_gpus, cache_mb, table.device_ptr, num_rows=num_rows, rank=0)
-        orc = oracle.OracleCache(cache_mb, dim, feat, node_color=color, num_colors=num_colors if with_color else 0, n_gpus=n_gpus,
-                                 distributed=distributed)
-        bad_total = 0
-        for b in range(5):
-            kind = rng.integers(0, 5)
-            n = int(rng.integers(0, 3000)) if kind else 0
-            if kind == 1:
-                idx = rng.integers(0, num_rows, size=n)                                   # duplicates
-            elif kind == 2:
-                idx = (rng.integers(0, max(num_rows // max(orc.num_sets, 1), 1), size=n) * orc.num_sets * (n_gpus if distributed else 1)) % num_rows  # one set
-            else:
-                idx = rng.choice(num_rows, size=min(n, num_rows), replace=False)
-            idx = idx.astype(np.int64)
-            bad = np.zeros(len(idx), dtype=bool)
-            if kind == 4 and len(idx):
-                bad = rng.random(len(idx)) < 0.05
-                idx[bad] = rng.choice([-1, num_rows, num_rows + 7, 2**40], size=int(bad.sum()))
-            good = ~bad
-            d_idx = torch.from_numpy(idx).cuda() if len(idx) else torch.zeros(1, dtype=torch.int64, device="cuda")
-            out = torch.full((max(len(idx), 1), dim), -2.0, dtype=torch.float32, device="cuda")
-            (cache.serve if distributed else cache.read_feature)(out.data_ptr(), d_idx.data_ptr(), len(idx))
-            orc.read_feature(idx[good], oracle.SCHED_HITS_FIRST, want_rows=False)      # the oracle never sees rejected ids
-            got = out.cpu().numpy()[: len(idx)]
-            assert got[good].tobytes() == feat[idx[good]].tobytes(), f"seed {seed} case {case} batch {b}"
-            assert np.all(got[bad] == 0.0)
-            bad_total += int(bad.sum())
-            assert cache.stats() == (orc.hit_cnt, orc.miss_cnt, bad_total), f"seed {seed} case {case} batch {b} (dim {dim}, G {n_gpus})"
-            keys, cnt, meta = cache.dump()
-            assert np.array_equal(keys, orc.keys()) and np.array_equal(cnt, orc.set_cnt())
-            if with_color:
-                cc = np.zeros(num_colors + 1, dtype=np.int32)
-                cache.get_cache_data(cc.ctypes.data, num_colors + 1)
-                assert np.array_equal(cc, orc.color_counters()) and np.array_equal(meta.astype(np.uint64), orc.color_meta())
-        cache.close()
-        table.close()
+def test_randomized_configs_match_oracle(hiplib, oracle, tmp_path, seed):
+    _fuzz_body.run(hiplib, oracle, tmp_path, seed)
+
+
+@pytest.mark.parametrize("seed", sorted(KNOBS))
+def test_randomized_configs_other_launch_shapes(tmp_path, seed):
+    """The same sweep on the development build with other grid / tile shapes of the two cache kernels (one process per shape: the
+    knobs are read when the library is loaded and handles are created)."""
+    spec = importlib.util.spec_from_file_location("coala_build", os.path.join(ROOT, "coala-gnn_amd", "build.py"))
+    bm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bm)
+    dev = bm.build_lib(dev=True)
+    env = dict(os.environ, COALA_HIP_LIB=dev, **KNOBS[seed])
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_fuzz_body.py"), str(seed), str(tmp_path)], env=env, capture_output=True,
+                         text=True, timeout=900)
+    assert out.returncode == 0 and f"fuzz seed {seed} ok" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]

@@ -76,7 +76,8 @@ def run(P, oracle, tmp_path, seed, cases=12):
                 rng.shuffle(ranges)
                 k = int(rng.integers(1, 4))
                 for part in range(k):
-                    cache.serve_fill_ranges(out.data_ptr(), d_idx.data_ptr(), n, ranges[part::k])
+                    if ranges[part::k]:      # (a fill after the batch has been covered is refused: nothing left to match it)
+                        cache.serve_fill_ranges(out.data_ptr(), d_idx.data_ptr(), n, ranges[part::k])
                 got = out.cpu().numpy()[:n].copy()
                 oth = other.cpu().numpy()
                 inside = np.zeros(n, dtype=bool)

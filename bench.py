@@ -283,10 +283,49 @@ def _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, dev
     graph = sampler.make_graph(indptr, indices)
     log(f"graph {args.rows} nodes / {indices.numel()} edges built in {time.time() - t0:.1f}s")
 
-    manager = COALA_GNN_Manager(node_distributor=None, num_ssds=1, page_size=args.dim * 4, num_elems=1024, ssd_read_offset=0,
-                                cache_size=args.cache_mb, batch_size=args.batch, fan_out=fanout, dim=args.dim,
-                                MPI_comm_manager=comm, device=device, cache_backend=backend, sim_buf=sim_ptr_owner,
-                                num_rows=args.rows, profile=True, cold_partitioned=cold_partitioned, exchange=args.exchange)
+    def make_manager(exchange):
+        return COALA_GNN_Manager(node_distributor=None, num_ssds=1, page_size=args.dim * 4, num_elems=1024, ssd_read_offset=0,
+                                 cache_size=args.cache_mb, batch_size=args.batch, fan_out=fanout, dim=args.dim,
+                                 MPI_comm_manager=comm, device=device, cache_backend=backend, sim_buf=sim_ptr_owner,
+                                 num_rows=args.rows, profile=True, cold_partitioned=cold_partitioned, exchange=exchange)
+
+    def first_fetch_is_exact(mgr, smp):
+        """One minibatch through the path, compared bit for bit with the table's formula (untimed)."""
+        lo = rank * args.batch
+        b = smp.sample(graph, train_ids[lo: lo + args.batch].to(device), step=10**9)
+        got = mgr.fetch_feature(b)[-1]
+        torch.cuda.synchronize()
+        return bool(torch.equal(got, feature_rows_torch(b[0], args.dim, args.seed)))
+
+    # N>1: the fused native exchange over RCCL has never seen two physical GPUs before the driver's run.  If it raises or delivers a
+    # wrong row on ANY rank, every rank falls back to the torch.distributed transport (same sequence, driven from Python) with
+    # sampler-order ids, and the line says so.  (A hang cannot be recovered in-process: the RankGuard ends the job non-zero.)
+    exchange_note = None
+    manager = None
+    try:
+        manager = make_manager(args.exchange)
+        ok = first_fetch_is_exact(manager, sampler) if (world > 1 and args.mode == "minibatch") else True
+        err = None if ok else "the first minibatch differs from the table"
+    except Exception as e:  # noqa: BLE001
+        if world == 1:
+            raise
+        ok, err = False, repr(e)
+    if world > 1:
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=comm.local_gloo_gather)   # a CPU group: usable whatever state RCCL is in
+        if int(flag[0]) == 0:
+            kind = getattr(manager, "exchange_kind", args.exchange or "native")
+            log(f"exchange '{kind}' failed its first-minibatch check on at least one rank ({err}): falling back to the torch transport")
+            if kind == "torch":
+                raise RuntimeError(f"parity self-check failed with the torch transport on rank {rank}: {err}")
+            exchange_note = f"torch (fallback: the native exchange failed its first-minibatch check: {err})"
+            manager = None
+            bucket = 0
+            os.environ["COALA_EXCHANGE"] = "torch"     # the managers of the later legs (epoch, fan-out 10,10) follow
+            sampler = NeighborSampler(fanout, seed=args.seed)
+            manager = make_manager("torch")
+            if not first_fetch_is_exact(manager, sampler):
+                raise RuntimeError(f"parity self-check failed on rank {rank} with the torch transport as well")
     cache = manager.COALA_GNN_Cache
     max_rows = manager.max_sample_size
     manager.sync_on_return = False  # stream-ordered fetches: the timed region is bracketed by synchronisations below
@@ -465,7 +504,7 @@ def _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, dev
                        "rows_per_step_per_gpu": round(rows_all / world / args.steps, 1),
                        "hit_ratio": round(hit_all / max(hit_all + miss_all, 1.0), 4),
                        "cache_backend": backend, **({"TEST_HOOK_single_device": True} if single_dev else {}),
-                       "exchange_transport": getattr(manager, "exchange_kind", None) if world > 1 else None,
+                       "exchange_transport": (exchange_note or getattr(manager, "exchange_kind", None)) if world > 1 else None,
                        "rccl_ranks": (getattr(manager.exchange, "rccl_ranks", None) or
                                       (dist.get_world_size(comm.nccl_cache_gather) if not single_dev else None)) if world > 1 else None,
                        "input_nodes": "bucketed by owner by the sampler (no routing pass, rows received in place)" if bucket else "sampler order",

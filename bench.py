@@ -302,6 +302,8 @@ def _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, dev
     # sampler-order ids, and the line says so.  (A hang cannot be recovered in-process: the RankGuard ends the job non-zero.)
     exchange_note = None
     manager = None
+    if world > 1:
+        guard.arm(240.0, "communicator set-up + first minibatch over the exchange")
     try:
         manager = make_manager(args.exchange)
         ok = first_fetch_is_exact(manager, sampler) if (world > 1 and args.mode == "minibatch") else True
@@ -326,6 +328,7 @@ def _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, dev
             manager = make_manager("torch")
             if not first_fetch_is_exact(manager, sampler):
                 raise RuntimeError(f"parity self-check failed on rank {rank} with the torch transport as well")
+    guard.arm(1500.0, "prewarm + timed region")
     cache = manager.COALA_GNN_Cache
     max_rows = manager.max_sample_size
     manager.sync_on_return = False  # stream-ordered fetches: the timed region is bracketed by synchronisations below

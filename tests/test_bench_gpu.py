@@ -15,6 +15,15 @@ REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
             "dtype", "data", "config", "roofline", "cpu_baseline"}
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return str(p)
+
+
 def _line(out):
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -41,7 +50,7 @@ def test_bench_single_gpu_contract():
 def test_bench_two_ranks_on_one_gpu_with_epoch_leg():
     env = dict(os.environ, COALA_BENCH_SINGLE_DEVICE="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29571", os.path.join(ROOT, "bench.py"), "--gpus", "2", *SMALL, "--epoch-prefetch-multi"]
+           "--master-port", _free_port(), os.path.join(ROOT, "bench.py"), "--gpus", "2", *SMALL, "--epoch-prefetch-multi"]
     d = _line(subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env))
     assert d["n_gpus"] == 2 and d["config"]["cache_backend"] == "nccl" and d["config"]["TEST_HOOK_single_device"] is True
     assert d["cpu_baseline"] is None and d["value"] > 0
@@ -61,7 +70,7 @@ def test_bench_rank_failure_is_visible():
     import time
     env = dict(os.environ, COALA_BENCH_SINGLE_DEVICE="1", COALA_BENCH_INJECT_FAIL="1:serial")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29573", os.path.join(ROOT, "bench.py"), "--gpus", "2", *SMALL, "--no-fanout-leg"]
+           "--master-port", _free_port(), os.path.join(ROOT, "bench.py"), "--gpus", "2", *SMALL, "--no-fanout-leg"]
     t0 = time.time()
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode != 0, "a failed rank was reported as success"

@@ -132,6 +132,7 @@ class COALA_GNN_DataLoader(torch.utils.data.DataLoader):
         self._side_stream = None
         self._sample_stream = None
         self._stop = threading.Event()   # set by close(): the producer gives up at its next queue hand-off
+        self._ahead = None               # serial mode: the sample of the next step, already enqueued (see _produce_one)
         self.producer_times = {"schedule": 0.0, "sample": 0.0, "fetch": 0.0, "queue_full": 0.0, "gpu_backlog": 0.0}
         self.refresh_counter = refresh_counter
         self.sampler = graph_sampler
@@ -167,31 +168,49 @@ class COALA_GNN_DataLoader(torch.utils.data.DataLoader):
     def __len__(self):
         return max(self.total_count, 0)
 
+    def _launch_sample(self):
+        """scheduler -> seeds -> sample ENQUEUED on the sampler's own stream (no host wait); -> (pending sample, its event)."""
+        is_last_iter = self.counter + 1 >= self.total_count
+        seeds = self.scheduler.run(is_last_iter)
+        if self._sample_stream is None:
+            self._sample_stream = torch.cuda.Stream(device=self.device)
+        with torch.cuda.stream(self._sample_stream):
+            pending = self.sampler.sample_begin(self.g, seeds.to(self.device))
+            ev = torch.cuda.Event()
+            ev.record()
+        return pending, ev
+
     def _produce_one(self):
         # last step of the epoch: do not launch a distributor thread past the end of the id list (SURVEY A.13: the
         # reference's is_last test compares a step counter with the id count and never fires)
-        is_last_iter = self.counter + 1 >= self.total_count
-        seeds = self.scheduler.run(is_last_iter)
-        if not self._sample_on_side_stream:
-            batch = self.sampler.sample(self.g, seeds.to(self.device))
-        else:
-            # Same order of work as the reference's __next__, one host thread -- but the sampler's kernels (and the seed copy)
-            # go to their own stream: they depend on nothing the training step of the previous iteration does, and on the
-            # caller's stream the host read-back at the end of the sampler would wait for that whole step to drain.
+        if self._sample_on_side_stream and hasattr(self.sampler, "sample_begin"):
+            # Same order of work as the reference's __next__, one host thread -- but the sampler's kernels (and the seed copy) go
+            # to their own stream, and the sample of step t+1 is enqueued right behind the fetch of step t: by the time the next
+            # __next__ asks for its counts they have long arrived, so the host never waits for the sampler and its kernels run
+            # beside the PCIe-bound fill instead of in front of it.  (The scheduler's call for step t+1 moves in front of the
+            # training step t; it touches nothing that step does: the colour snapshot stays ordered behind fetch t on the stream.)
+            if self._ahead is None:
+                self._ahead = self._launch_sample()
+            pending, ev = self._ahead
+            self._ahead = None
+            batch = self.sampler.sample_end(pending)
             cur = torch.cuda.current_stream()
-            if self._sample_stream is None:
-                self._sample_stream = torch.cuda.Stream(device=self.device)
-            with torch.cuda.stream(self._sample_stream):
-                batch = self.sampler.sample(self.g, seeds.to(self.device))
-                ev = torch.cuda.Event()
-                ev.record()
             cur.wait_event(ev)
             for t in _device_tensors(batch):
                 t.record_stream(cur)  # allocated on the sampler's stream, used by fetch and training on this one
+            self.counter += 1
+            out = self.COALA_GNN_Manager.fetch_feature(batch)
+            if self.counter < self.total_count:
+                self._ahead = self._launch_sample()
+            return out
+        is_last_iter = self.counter + 1 >= self.total_count
+        seeds = self.scheduler.run(is_last_iter)
+        batch = self.sampler.sample(self.g, seeds.to(self.device))
         self.counter += 1
         return self.COALA_GNN_Manager.fetch_feature(batch)
 
     def _end_of_epoch(self):
+        self._ahead = None
         self.scheduler.drain()  # the reference resets while a distributor thread may still run (SURVEY A.13)
         self.node_distributor.reset()
         self.counter = 0

@@ -156,6 +156,12 @@ class NeighborSampler(object):
 
     def sample(self, g, seed_nodes, step=None):
         """-> (input_nodes, output_nodes, blocks), blocks[0] is the input layer (DGL order)."""
+        return self.sample_end(self.sample_begin(g, seed_nodes, step))
+
+    def sample_begin(self, g, seed_nodes, step=None):
+        """Enqueue the sample on the current stream and return without waiting (the kernels read their sizes from the device);
+        sample_end(pending) collects the counts and builds the blocks.  A caller with something else to enqueue in between -- the
+        loader launches step t+1's sample right behind step t's fetch -- never waits for the sampler at all."""
         if isinstance(g, tuple):
             g = CSCGraph(*g)
         seeds = seed_nodes.to(g.device, dtype=torch.int64).contiguous()
@@ -170,26 +176,34 @@ class NeighborSampler(object):
         src_p = (C.c_void_p * L)(*[t.data_ptr() for t in src])
         nbr_p = (C.c_void_p * L)(*[t.data_ptr() for t in nbr])
         fan = (C.c_int32 * L)(*rev)
-        n_src = (C.c_int64 * L)()
         st = self.step if step is None else int(step)
         G = self.bucket_by_owner
         bk = None
+        extra = None
         if G > 0:
             bucketed = torch.empty(max(caps[L], 1), dtype=torch.int64, device=g.device)
             counts = torch.empty(G, dtype=torch.int64, device=g.device)
             dst_in_src = torch.empty(max(caps[L - 1], 1), dtype=torch.int32, device=g.device)
             bk = _capi.SamplerBucketing(G, 0, bucketed.data_ptr(), counts.data_ptr(), dst_in_src.data_ptr())
+            extra = (bucketed, counts, dst_in_src)
         ticket = C.c_int64(-1)
-        # one kernel launch; the call returns when the per-layer counts have arrived in pinned host memory (event wait)
-        _capi.check(_lib.coala_sampler_sample(g._h, seeds.data_ptr(), n, fan, L, self.seed, st, src_p, nbr_p, n_src,
+        # three launches per layer, nothing else: no host wait here (n_src_host = NULL)
+        _capi.check(_lib.coala_sampler_sample(g._h, seeds.data_ptr(), n, fan, L, self.seed, st, src_p, nbr_p, None,
                                               C.byref(bk) if bk is not None else None, C.byref(ticket), current_stream()))
-        counts_host = None
-        if G > 0:
-            ch = (C.c_int64 * G)()
-            _capi.check(_lib.coala_sampler_wait(g._h, ticket.value, None, ch))
-            counts_host = list(ch)
         if step is None:
             self.step += 1
+        return (g, seeds, n, rev, src, nbr, extra, ticket.value)
+
+    def sample_end(self, pending):
+        """Wait for the counts of a sample_begin (an event wait: only for that call's kernels) and build the blocks."""
+        g, seeds, n, rev, src, nbr, extra, ticket = pending
+        L, G = len(rev), self.bucket_by_owner
+        n_src = (C.c_int64 * L)()
+        ch = (C.c_int64 * G)() if G > 0 else None
+        _capi.check(_lib.coala_sampler_wait(g._h, ticket, n_src, ch))
+        counts_host = list(ch) if G > 0 else None
+        if G > 0:
+            bucketed, counts, dst_in_src = extra
         blocks = []
         n_dst = n
         for l in range(L):

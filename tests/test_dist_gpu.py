@@ -563,3 +563,27 @@ def test_split_serve_equals_one_serve(hiplib, oracle, dim, tier, monkeypatch):
     a.close(); b.close()
     if table is not None:
         table.close()
+
+
+def test_native_fetch_over_rccl_two_gpus():
+    """The fused native fetch over a REAL RCCL communicator between two distinct GPUs (bucketed and routed), against the table.
+    Needs two visible GPUs: skipped on the one-GPU development / round-end boxes; it is what the driver's multi-GPU node exercises
+    through bench.py (whose first-minibatch check is the same comparison)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL cannot place two ranks on one device)")
+    import os
+    import socket
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", COALA_TEST_REAL_RCCL="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(here, "_dist_gpu_worker.py"), "nccl"], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    for r, p in enumerate(procs):
+        out, _ = p.communicate(timeout=600)
+        assert p.returncode == 0 and f"rank {r} ok" in out, out[-3000:]

@@ -22,6 +22,7 @@
 //                     "winner") publishes key, colour and line; every miss streams its row from the cold tier (pinned
 //                     host over PCIe, or HBM) into the output.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cstdarg>
@@ -763,6 +764,8 @@ void drain_events(coala_cache* h) {
     h->ev_live.clear();
 }
 
+// COALA_FLAG_PROFILE: the kernel's own begin / end timestamps (hipExtLaunchKernelGGL attaches the two events to the dispatch
+// itself), i.e. what rocprofv3 reports for the launch -- a separate hipEventRecord bracket adds the 2-5 us between two packets.
 struct ProfScope {
     coala_cache* h; hipStream_t s; int kind; uint64_t rows; hipEvent_t a = nullptr, b = nullptr; bool on;
     ProfScope(coala_cache* h_, hipStream_t s_, int kind_, uint64_t rows_) : h(h_), s(s_), kind(kind_), rows(rows_) {
@@ -771,14 +774,16 @@ struct ProfScope {
             if (h->ev_live.size() >= 8192) drain_events(h);
             a = take_event(h); b = take_event(h);
             on = a && b;
-            if (on) { (void)hipEventRecord(a, s); h->last_stream = s; }
+            if (on) h->last_stream = s;
         }
     }
+    template <typename K, typename... Args>
+    void launch(K kernel, dim3 grid, dim3 block, Args... args) {
+        if (on) hipExtLaunchKernelGGL(kernel, grid, block, 0, s, a, b, 0, args...);
+        else hipLaunchKernelGGL(kernel, grid, block, 0, s, args...);
+    }
     ~ProfScope() {
-        if (on) {
-            (void)hipEventRecord(b, s);
-            h->ev_live.push_back({a, b, kind, rows});
-        }
+        if (on) h->ev_live.push_back({a, b, kind, rows});
     }
 };
 
@@ -1064,16 +1069,16 @@ static int read_feature_impl(coala_cache_t* h, float* out, const int64_t* idx, i
             const bool full = (VEC == 4) && ((int)d.dim == CD);
             const dim3 grid(grid_for(chunks, h->k1_waves, h->k1_grid_cap)), block(64 * h->k1_waves);
             if (redir) {
-                hipLaunchKernelGGL((probe_gather_kernel<CD, VEC, 4, false, 0, true>), grid, block, 0, s, idx, out, n, gen, grid.x, d, rd);
+                ps.launch(probe_gather_kernel<CD, VEC, 4, false, 0, true>, grid, block, idx, out, n, gen, (uint32_t)grid.x, d, rd);
             } else if (h->k1_passes == 2) {
                 using G2 = Geo<CD, VEC, 2>;
                 const int64_t chunks2 = (n + G2::R - 1) / G2::R;
                 const dim3 grid2(grid_for(chunks2, h->k1_waves, h->k1_grid_cap));
-                hipLaunchKernelGGL((probe_gather_kernel<CD, VEC, 2, false>), grid2, block, 0, s, idx, out, n, gen, grid2.x, d, rd);
+                ps.launch(probe_gather_kernel<CD, VEC, 2, false>, grid2, block, idx, out, n, gen, (uint32_t)grid2.x, d, rd);
             } else if (full) {
-                hipLaunchKernelGGL((probe_gather_kernel<CD, VEC, 4, true>), grid, block, 0, s, idx, out, n, gen, grid.x, d, rd);
+                ps.launch(probe_gather_kernel<CD, VEC, 4, true>, grid, block, idx, out, n, gen, (uint32_t)grid.x, d, rd);
             } else {
-                hipLaunchKernelGGL((probe_gather_kernel<CD, VEC, 4, false>), grid, block, 0, s, idx, out, n, gen, grid.x, d, rd);
+                ps.launch(probe_gather_kernel<CD, VEC, 4, false>, grid, block, idx, out, n, gen, (uint32_t)grid.x, d, rd);
             }
         }
         if ((phases & kPhaseFill) && fill_rows > 0) {
@@ -1083,8 +1088,8 @@ static int read_feature_impl(coala_cache_t* h, float* out, const int64_t* idx, i
                 ProfScope ps(h, s, 2, 0);
                 const int64_t tiles = ((int64_t)rs.total + tile_rows - 1) / tile_rows;
                 const dim3 grid(grid_for(tiles, 4, h->k2_grid_cap));
-                if (redir) hipLaunchKernelGGL((miss_fill_kernel<CD, VEC, true>), grid, dim3(256), 0, s, d, idx, out, tile_rows, gen, rs, rd);
-                else hipLaunchKernelGGL((miss_fill_kernel<CD, VEC, false>), grid, dim3(256), 0, s, d, idx, out, tile_rows, gen, rs, rd);
+                if (redir) ps.launch(miss_fill_kernel<CD, VEC, true>, grid, dim3(256), d, idx, out, tile_rows, gen, rs, rd);
+                else ps.launch(miss_fill_kernel<CD, VEC, false>, grid, dim3(256), d, idx, out, tile_rows, gen, rs, rd);
                 return COALA_OK;
             });
         }

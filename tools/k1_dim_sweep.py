@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """probe_gather_kernel hit-ratio sweep for every line size (cache_dim 128 / 256 / 512 / 1024): the product call
-(coala_cache_read_feature, COALA_FLAG_PROFILE events around K1) on a batch of unique ids of which a given share is cached.
+(coala_cache_read_feature, COALA_FLAG_PROFILE: events attached to the K1 launch) on a batch of unique ids of which a given share is cached.
 Cold tier in HBM so that the fill between the timed launches is short; the batch is re-warmed before every measurement."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "coala-gnn_amd")
 import torch
 import COALA_GNN_Pybind as P
 torch.cuda.set_device(0)
-print("# tools/k1_dim_sweep.py: K1 alone (hipEvents incl. ~4.6 us bracket), algorithmic bytes = rows x 264 B + hits x 2 x dim x 4 B")
+print("# tools/k1_dim_sweep.py: K1 alone (HIP events attached to the launch: the kernel's own begin -> end), algorithmic bytes = rows x 264 B + hits x 2 x dim x 4 B")
 for dim, n, rows in ((128, 1081344, 8_000_000), (256, 262144, 4_000_000), (512, 123904, 4_000_000), (1024, 36864, 2_000_000), (1024, 123904, 2_000_000)):
     table = torch.rand((rows, dim), dtype=torch.float32, device="cuda")
     ctrl = P.SSD_GNN_SSD_Controllers(1, 4096, 1024, 0, 0, dim, True)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """probe_gather_kernel IN SITU: the default bench workload (IGB-medium shape, fan-out 5,5, isolated 4 GiB cache, pinned-host cold
 tier), one cache handle per variant (COALA_K1_* environment knobs are read at handle creation), 400 warm-up minibatches, then
-the kernel's average duration over 200 timed minibatches by HIP events (COALA_FLAG_PROFILE) -- i.e. with the cold fill of the
+the kernel's average duration over 200 timed minibatches by HIP events attached to its launches (COALA_FLAG_PROFILE) -- i.e. with the cold fill of the
 previous step in front of every launch, which the tools/k1_bench micro-benchmark does not have.
 
   python tools/k1_insitu.py "GRID=2048" "GRID=1024" "GRID=2048,PASSES=2" ...      (knob list per variant, comma separated)"""
@@ -96,7 +96,7 @@ for rep in range(int(os.environ.get("REPS", 2))):
         hit, miss, _ = cache.stats()
         alg = p.gather_rows * 264 + p.gather_hits * 2 * dim * 4
         us = p.gather_ms / p.gather_launches * 1e3
-        print(f"{v:40s} K1 {us:7.2f} us (events, bracket {p.event_overhead_us:.2f} us)  {alg / p.gather_launches / us / 1e3:7.1f} GB/s = "
+        print(f"{v:40s} K1 {us:7.2f} us (events attached to the launch)  {alg / p.gather_launches / us / 1e3:7.1f} GB/s = "
               f"{alg / p.gather_launches / us / 1e3 / 80:5.1f} % of 8 TB/s   K2 {p.fill_ms / p.fill_launches * 1e3:8.1f} us   step {wall:.4f} ms   hit {hit / (hit + miss):.4f}", flush=True)
         if os.environ.get("ALLHIT"):   # the BASELINE section 4 micro-benchmark on the same handle: 36,864 unique ids, every row a hit
             ids = torch.randperm(rows, device="cuda", generator=torch.Generator(device="cuda").manual_seed(12345))[:36864]

@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box: everything under profiles/ for one round, in one go (about 6 GPU-minutes).  Summaries land in gpurun_out/profiles_out/.
+# GPU box: everything under profiles/ for one round, in one go (about 4 GPU-minutes).  Summaries land in gpurun_out/profiles_out/.
 R=${GRAFT_REPO_ROOT:-$PWD}
 export ROUND=${ROUND:-r02} TMPDIR=/tmp
 O=$R/gpurun_out/profiles_out
@@ -9,8 +9,10 @@ bash tools/profile_round.sh > $R/gpurun_out/profile_default.log 2>&1; echo "defa
 TAG=allhit BENCH_ARGS="--rows 2000000 --mode allhit --prewarm 3 --steps 100 --no-cpu-baseline --epoch-steps 0 --no-fanout-leg --no-color-affinity-leg" bash tools/profile_round.sh > $R/gpurun_out/profile_allhit.log 2>&1; echo "allhit profile rc=$?"
 bash tools/dist_profile.sh > /dev/null 2>&1; grep -v amdgpu.ids $R/gpurun_out/r02_dist_step_kernels.txt > $O/${ROUND}_dist_step_kernels.txt; echo "dist rc=$?"
 COALA_K1_GRID=8192 bash tools/k1_stages_profile.sh > /dev/null 2>&1; grep -v "amdgpu.ids\|^[EW]2026" $R/gpurun_out/r02_k1_fixed_cost.txt > $O/${ROUND}_k1_fixed_cost.txt; echo "k1 stages rc=$?"
+bash tools/k1_variants.sh > /dev/null 2>&1; cp $R/gpurun_out/r02_k1_variants.txt $O/${ROUND}_k1_variants.txt; echo "k1 variants rc=$?"
 python3 tools/k1_dim_sweep.py 2>&1 | grep -v amdgpu.ids > $O/${ROUND}_k1_hit_sweep.txt; echo "dim sweep rc=$?"
 python3 tools/fetch_gap_probe.py 2>&1 | grep -v amdgpu.ids > $O/${ROUND}_prefetch_fetch_gaps.txt; echo "gap probe rc=$?"
 (echo "# tools/sampler_fanout_probe.py (MI355X; 10 M-node power-law graph, 1024 seeds; round 1: 0.107 / 0.110 / 0.210 / 0.197 ms for 5,5 / 10,10 / 15,10,5 / 10,10,10)"; python3 tools/sampler_fanout_probe.py 2>&1 | grep -v amdgpu.ids) > $O/${ROUND}_sampler_fanouts.txt; echo "sampler rc=$?"
+python3 tools/backend_compare_probe.py 2>/dev/null | grep "^{" | python3 -m json.tool > $O/${ROUND}_backend_compare.json; echo "backend compare rc=$?"
 for g in community powerlaw; do python3 tools/color_affinity_probe.py --graph $g 2>/dev/null | grep "^{" | python3 -m json.tool > $O/${ROUND}_color_affinity_$g.json; echo "colour $g rc=$?"; done
 ls -la $O

@@ -156,24 +156,24 @@ class AllToAllExchange(object):
         self._pending = (n, node, mp, send_c, recv_c, recv_ids, total_recv)
         self.last_send_counts, self.last_recv_counts = send_c, recv_c
 
-    def read_feature(self, ops, out_ptr, req_ptr, max_index):
-        """probe + rounds of {fill, row exchange} + un-permute.  ssd_gnn_cache.cuh:132-174 / COALA_GNN_Manager.py:167-209."""
-        n, node, mp, send_c, recv_c, recv_ids, total_recv = self._pending
-        self._pending = None
+    def _serve_in_rounds(self, ops, n, send_c, recv_c, recv_ids, own_out_ptr, own_map_ptr, rows_dst):
+        """Owner and requester side of one step after the ids have arrived: probe the ONE batch (own segment redirected to
+        own_out_ptr through own_map_ptr), then per round {cold fill of slice k of every peer's segment | rows of slice k into
+        rows_dst on the side stream}.  -> (requester-side slices per round, events to wait for per round)."""
         G, me, dim = self.world, self.rank, self.dim
+        total_recv = int(sum(recv_c))
         sdis = [sum(send_c[:p]) for p in range(G)]
         rdis = [sum(recv_c[:p]) for p in range(G)]
         rows_send = self._buf("rows_send", total_recv * dim, torch.float32)[: max(total_recv, 1) * dim].view(-1, dim)
-        rows_recv = self._buf("rows_recv", n * dim, torch.float32)[: max(n, 1) * dim].view(-1, dim)
         K = 1 if G == 1 else self.rounds
         if total_recv:
             # one batch per owner and step: the concatenation in source-rank order; the own segment lands in the caller's tensor
             ops.serve_probe_redirect(rows_send.data_ptr(), recv_ids.data_ptr(), total_recv, rdis[me], rdis[me] + recv_c[me],
-                                     out_ptr, mp.data_ptr() + sdis[me] * 8)
+                                     own_out_ptr, own_map_ptr)
         fill = _round_slices(recv_c, rdis, K, me)      # owner side: positions of the batch / rows of rows_send
-        land = _round_slices(send_c, sdis, K, me)      # requester side: rows of rows_recv (bucket order, like `node`)
+        land = _round_slices(send_c, sdis, K, me)      # requester side: rows of rows_dst (bucket order)
         cur = torch.cuda.current_stream() if rows_send.is_cuda else None
-        timed = self.profile and rows_recv.is_cuda and G > 1
+        timed = self.profile and rows_send.is_cuda and G > 1
         ev_t = None
         done = []
         for k in range(K):
@@ -183,36 +183,40 @@ class AllToAllExchange(object):
                     rng.append((rdis[me], rdis[me] + recv_c[me]))  # own segment: nobody waits for it on a link
                 ops.serve_fill_ranges(rows_send.data_ptr(), recv_ids.data_ptr(), total_recv, rng)
             if G == 1:
-                continue
+                continue   # (every rank of a larger group takes part in every round, whatever its own batch size: it is a collective)
             if self._side is not None:
                 ev = torch.cuda.Event()
                 ev.record(cur)
                 self._side.wait_event(ev)
-                with torch.cuda.stream(self._side):
-                    if timed and k == 0:
-                        ev_t = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                        ev_t[0].record()
-                    self._a2a_slices(rows_recv, land[k], rows_send, fill[k])
-                    if timed and k == K - 1:
-                        ev_t[1].record()
-                    e2 = torch.cuda.Event()
-                    e2.record()
-                done.append(e2)
-            else:
+            with torch.cuda.stream(self._side) if self._side is not None else contextlib.nullcontext():
                 if timed and k == 0:
                     ev_t = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                     ev_t[0].record()
-                self._a2a_slices(rows_recv, land[k], rows_send, fill[k])
+                self._a2a_slices(rows_dst if rows_dst is not None else rows_send[:0], land[k], rows_send, fill[k])
                 if timed and k == K - 1:
                     ev_t[1].record()
-                done.append(None)
+                e2 = None
+                if self._side is not None:
+                    e2 = torch.cuda.Event()
+                    e2.record()
+                done.append(e2)
         if timed and ev_t is not None:
             self._row_events.append(ev_t)
             self.rows_a2a_calls += 1
             self.remote_rows_in += n - int(send_c[me])
-        for k in range(K if G > 1 else 0):  # un-permute round by round as the rows arrive
-            if done[k] is not None:
-                cur.wait_event(done[k])
+        return land, done, cur, sdis
+
+    def read_feature(self, ops, out_ptr, req_ptr, max_index):
+        """probe + rounds of {fill, row exchange} + un-permute.  ssd_gnn_cache.cuh:132-174 / COALA_GNN_Manager.py:167-209."""
+        n, node, mp, send_c, recv_c, recv_ids, total_recv = self._pending
+        self._pending = None
+        me = self.rank
+        rows_recv = self._buf("rows_recv", n * self.dim, torch.float32)[: max(n, 1) * self.dim].view(-1, self.dim)
+        sdis_me = sum(send_c[:me])
+        land, done, cur, _ = self._serve_in_rounds(ops, n, send_c, recv_c, recv_ids, out_ptr, mp.data_ptr() + sdis_me * 8, rows_recv)
+        for k, e2 in enumerate(done):  # un-permute round by round as the rows arrive
+            if e2 is not None:
+                cur.wait_event(e2)
             ops.scatter_ranges(out_ptr, rows_recv.data_ptr(), mp.data_ptr(), [r for r in land[k] if r[1] > r[0]])
 
     def fetch(self, ops, out_ptr, idx_ptr, n, max_index=0):
@@ -236,53 +240,16 @@ class AllToAllExchange(object):
             raise RuntimeError(f"the bucket counts sum to {sum(send_c)} for a batch of {n} ids")
         self.last_send_counts, self.last_recv_counts = send_c, recv_c
         total_recv = int(sum(recv_c))
-        sdis = [sum(send_c[:p]) for p in range(G)]
-        rdis = [sum(recv_c[:p]) for p in range(G)]
         node = _tensor_view(idx_ptr, n, torch.int64, self.counts)
         out = _tensor_view(out_ptr, n * dim, torch.float32, self.counts).view(-1, dim) if n else None
         recv_ids = self._buf("recv_ids", total_recv, torch.int64)
         self._a2a(recv_ids[:total_recv], node[:n], recv_c, send_c)
-        rows_send = self._buf("rows_send", total_recv * dim, torch.float32)[: max(total_recv, 1) * dim].view(-1, dim)
-        K = 1 if G == 1 else self.rounds
-        if total_recv:
-            ops.serve_probe_redirect(rows_send.data_ptr(), recv_ids.data_ptr(), total_recv, rdis[me], rdis[me] + recv_c[me],
-                                     int(out_ptr) + sdis[me] * dim * 4, 0)
-        fill = _round_slices(recv_c, rdis, K, me)
-        land = _round_slices(send_c, sdis, K, me)
-        cur = torch.cuda.current_stream() if rows_send.is_cuda else None
-        timed = self.profile and rows_send.is_cuda and G > 1
-        ev_t = None
-        done = []
-        for k in range(K):
-            if total_recv:
-                rng = [r for r in fill[k] if r[1] > r[0]]
-                if k == K - 1 and recv_c[me]:
-                    rng.append((rdis[me], rdis[me] + recv_c[me]))
-                ops.serve_fill_ranges(rows_send.data_ptr(), recv_ids.data_ptr(), total_recv, rng)
-            if G == 1:
-                continue
-            dst = out if out is not None else rows_send[:0]   # a rank with an empty batch still takes part in the collective
-            if self._side is not None:
-                ev = torch.cuda.Event()
-                ev.record(cur)
-                self._side.wait_event(ev)
-            with torch.cuda.stream(self._side) if self._side is not None else contextlib.nullcontext():
-                if timed and k == 0:
-                    ev_t = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                    ev_t[0].record()
-                self._a2a_slices(dst, land[k], rows_send, fill[k])
-                if timed and k == K - 1:
-                    ev_t[1].record()
-                if self._side is not None:
-                    e2 = torch.cuda.Event()
-                    e2.record()
-                    done.append(e2)
-        if timed and ev_t is not None:
-            self._row_events.append(ev_t)
-            self.rows_a2a_calls += 1
-            self.remote_rows_in += n - int(send_c[me])
+        # bucket order IS the caller's order: the own bucket sits at its offset of `out`, every peer's rows land at theirs
+        own_out = int(out_ptr) + sum(send_c[:me]) * dim * 4
+        _, done, cur, _ = self._serve_in_rounds(ops, n, send_c, recv_c, recv_ids, own_out, 0, out)
         for e2 in done:
-            cur.wait_event(e2)
+            if e2 is not None:
+                cur.wait_event(e2)
 
 
 def _tensor_view(ptr, numel, dtype, like):

@@ -394,7 +394,7 @@ __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src) {
 
 template <int CD, int VEC, bool REDIR = false, int NP = 4>
 __global__ __launch_bounds__(256) void miss_fill_kernel(CacheDev c, const int64_t* __restrict__ idx, float* __restrict__ out,
-                                                        int tile_rows, uint32_t gen, RangeSet rs, Redirect rd) {
+                                                        int tile_rows, int sparse_max, uint32_t gen, RangeSet rs, Redirect rd) {
     // Works on the batch positions of `rs` (the whole batch = one range, or the slices of a serve split into several fills),
     // walked as one dense virtual index space.  A wave reads the verdicts of tile_rows rows at once (one byte per lane;
     // tile_rows = R or 64) and then works through the tile chunk by chunk (R rows), skipping chunks without a miss on a scalar
@@ -436,60 +436,55 @@ __global__ __launch_bounds__(256) void miss_fill_kernel(CacheDev c, const int64_
         my_miss += (st == 1);
         my_bad += (st == 2);
         if (!tile_mask) continue;
-        for (int ck = 0; ck < chunks_per_tile; ++ck) {
-            const uint32_t live_mask = (uint32_t)(tile_mask >> (ck * R)) & ((1u << R) - 1u);
-            if (!live_mask) continue;
-            const int lane0 = ck * R;              // lanes lane0 .. lane0+R-1 hold this chunk's rows
-            // ---- the chunk's lanes holding a miss: rank it inside its set and pick the way
-            uint32_t slot_l = 0, win_l = 0;
-            uint64_t id_l = 0;
-            int64_t drow_l = (int64_t)pos_l;       // destination row; < 0 encodes row -(v+1) of rd.out
-            if (st == 1 && lane >= lane0 && lane < lane0 + R) {
-                id_l = (uint64_t)idx[pos_l];
-                if (REDIR && (int64_t)pos_l >= rd.begin && (int64_t)pos_l < rd.end)
-                    drow_l = -((rd.row_map ? rd.row_map[(int64_t)pos_l - rd.begin] : (int64_t)pos_l - rd.begin) + 1);
-                const uint64_t set = set_of(c, id_l);
-                uint32_t cur = (uint32_t)c.set_head[set]; // tagged with this generation: this row was pushed on it by K1
-                uint32_t total = 0, rank = 0;
-                while (cur) {
-                    const uint32_t p2 = cur - 1;
-                    ++total;
-                    rank += (p2 < pos_l) ? 1u : 0u;
-                    cur = c.miss_link[p2] & ~kLinkMiss;
-                }
-                // the cursor before this batch: the set's first-ranked miss advances it below, tagged with the generation
-                const uint64_t cv = __hip_atomic_load(c.set_cnt + set, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t cnt0 = ((uint32_t)(cv >> 32) == gen) ? (uint32_t)cv - total : (uint32_t)cv;
-                if (rank == 0) __hip_atomic_store(c.set_cnt + set, ((uint64_t)gen << 32) | (uint32_t)(cnt0 + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t way = (cnt0 + rank) & (COALA_WAYS - 1);              // isolated_cache.h:203
-                slot_l = (uint32_t)(set * COALA_WAYS) + way;
-                win_l = (rank + COALA_WAYS >= total) ? 1u : 0u;                     // nobody later in the batch lands here
-                if (win_l) {
-                    c.keys[slot_l] = id_l;                                          // isolated_cache.h:434
-                    if (c.color_counters) {
-                        // the pre-batch occupant leaves (:427-429), the winner enters (:437-441); rows that were inserted
-                        // and overwritten again inside this batch cancel out
-                        const int32_t col = c.node_color[id_l];
-                        atomicSub(c.color_counters + c.color_meta[slot_l], 1);
-                        atomicAdd(c.color_counters + col, 1);
-                        c.color_meta[slot_l] = (uint32_t)col;
-                    }
+        // ---- a lane holding a miss ranks it inside its set and picks the way
+        uint32_t slot_l = 0, win_l = 0;
+        uint64_t id_l = 0;
+        int64_t drow_l = (int64_t)pos_l;       // destination row; < 0 encodes row -(v+1) of rd.out
+        auto rank_mine = [&]() {
+            id_l = (uint64_t)idx[pos_l];
+            if (REDIR && (int64_t)pos_l >= rd.begin && (int64_t)pos_l < rd.end)
+                drow_l = -((rd.row_map ? rd.row_map[(int64_t)pos_l - rd.begin] : (int64_t)pos_l - rd.begin) + 1);
+            const uint64_t set = set_of(c, id_l);
+            uint32_t cur = (uint32_t)c.set_head[set]; // tagged with this generation: this row was pushed on it by K1
+            uint32_t total = 0, rank = 0;
+            while (cur) {
+                const uint32_t p2 = cur - 1;
+                ++total;
+                rank += (p2 < pos_l) ? 1u : 0u;
+                cur = c.miss_link[p2] & ~kLinkMiss;
+            }
+            // the cursor before this batch: the set's first-ranked miss advances it below, tagged with the generation
+            const uint64_t cv = __hip_atomic_load(c.set_cnt + set, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t cnt0 = ((uint32_t)(cv >> 32) == gen) ? (uint32_t)cv - total : (uint32_t)cv;
+            if (rank == 0) __hip_atomic_store(c.set_cnt + set, ((uint64_t)gen << 32) | (uint32_t)(cnt0 + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t way = (cnt0 + rank) & (COALA_WAYS - 1);              // isolated_cache.h:203
+            slot_l = (uint32_t)(set * COALA_WAYS) + way;
+            win_l = (rank + COALA_WAYS >= total) ? 1u : 0u;                     // nobody later in the batch lands here
+            if (win_l) {
+                c.keys[slot_l] = id_l;                                          // isolated_cache.h:434
+                if (c.color_counters) {
+                    // the pre-batch occupant leaves (:427-429), the winner enters (:437-441); rows that were inserted
+                    // and overwritten again inside this batch cancel out
+                    const int32_t col = c.node_color[id_l];
+                    atomicSub(c.color_counters + c.color_meta[slot_l], 1);
+                    atomicAdd(c.color_counters + col, 1);
+                    c.color_meta[slot_l] = (uint32_t)col;
                 }
             }
-            // ---- every lane learns the rows of its pass
+        };
+        // ---- stream up to R missed rows: pass p of this lane's half-wave moves the row held by lane srcl[p]
+        auto move_group = [&](const int (&srcl)[G::PASSES], const bool (&live)[G::PASSES]) {
             V val[G::PASSES][G::VPL];
             uint32_t slot_[G::PASSES];
             uint64_t id[G::PASSES];
             int64_t drow[G::PASSES];
-            bool live[G::PASSES], winner[G::PASSES];
+            bool winner[G::PASSES];
 #pragma unroll
             for (int p = 0; p < G::PASSES; ++p) {
-                const int q = p * G::RPP + sub;
-                live[p] = (live_mask >> q) & 1;
-                slot_[p] = (uint32_t)__shfl((int)slot_l, lane0 + q);
-                winner[p] = __shfl((int)win_l, lane0 + q) != 0;
-                id[p] = shfl64(id_l, lane0 + q);
-                drow[p] = (int64_t)shfl64((uint64_t)drow_l, lane0 + q);
+                slot_[p] = (uint32_t)__shfl((int)slot_l, srcl[p]);
+                winner[p] = __shfl((int)win_l, srcl[p]) != 0;
+                id[p] = shfl64(id_l, srcl[p]);
+                drow[p] = (int64_t)shfl64((uint64_t)drow_l, srcl[p]);
             }
 #pragma unroll
             for (int p = 0; p < G::PASSES; ++p) {
@@ -513,6 +508,41 @@ __global__ __launch_bounds__(256) void miss_fill_kernel(CacheDev c, const int64_
                         if (winner[p]) nt_store(val[p][v], line + u);
                     }
                 }
+            }
+        };
+        int srcl[G::PASSES];
+        bool live[G::PASSES];
+        if (__builtin_popcountll(tile_mask) <= sparse_max) {
+            // Few misses in this tile (the multi-GPU steady state): walking it chunk by chunk would stream one row at a time and
+            // leave the PCIe pipe half empty (16 % misses: 49 GB/s, 4 %: 39 GB/s).  Rank every missed row of the tile at once,
+            // then stream them R at a time, compacted.
+            if (st == 1) rank_mine();
+            uint64_t m = tile_mask;
+            while (m) {
+#pragma unroll
+                for (int p = 0; p < G::PASSES; ++p) {
+                    int l0 = -1, l1 = -1;
+                    if (m) { l0 = __builtin_ctzll(m); m &= m - 1; }
+                    if (G::RPP == 2 && m) { l1 = __builtin_ctzll(m); m &= m - 1; }
+                    const int l = (G::RPP == 2 && sub) ? l1 : l0;
+                    live[p] = l >= 0;
+                    srcl[p] = l >= 0 ? l : 0;
+                }
+                move_group(srcl, live);
+            }
+        } else {
+            for (int ck = 0; ck < chunks_per_tile; ++ck) {
+                const uint32_t live_mask = (uint32_t)(tile_mask >> (ck * R)) & ((1u << R) - 1u);
+                if (!live_mask) continue;
+                const int lane0 = ck * R;              // lanes lane0 .. lane0+R-1 hold this chunk's rows
+                if (st == 1 && lane >= lane0 && lane < lane0 + R) rank_mine();
+#pragma unroll
+                for (int p = 0; p < G::PASSES; ++p) {
+                    const int q = p * G::RPP + sub;
+                    live[p] = (live_mask >> q) & 1;
+                    srcl[p] = lane0 + q;
+                }
+                move_group(srcl, live);
             }
         }
       }
@@ -706,6 +736,7 @@ struct coala_cache {
     int64_t open_filled_rows = 0;
     Redirect open_redirect{0, 0, nullptr, nullptr};       // the open batch's redirect (set by the probe, reused by its fills)
     int k2_tile_rows = 0;                 // rows per verdict tile of K2: 64 for a host cold tier, 0 = one chunk (COALA_K2_TILE_ROWS)
+    int k2_sparse_max = 0;                // tiles with at most this many misses are streamed compacted (host tier; 0 = never)
     int k1_passes = 4;                    // rows(-pairs) in flight per wave in K1 (tunable: COALA_K1_PASSES = 2 | 4)
     int k1_grid_cap = 16384;              // K1 blocks: one chunk per wave up to 131,072 rows.  Measured (tools/k1_insitu.py, tools/k1_bench): 28.5 k rows at 32 %
                                           // hits in situ: 2048 blocks -> 22.3 us, 4096 -> 20.7, 8192 -> 20.6; all-hit 36,864 rows: 53.8 / 53.1 / 51.4 us;
@@ -937,9 +968,13 @@ int coala_cache_create(const coala_cache_config_t* cfg, coala_cache_t** out) {
             const int host_blocks = std::min(64, std::max(16, 16 * 1024 / (int)d.cache_dim));
             h->k2_grid_cap = host_tier ? host_blocks : kStatBlocks;
             h->k2_tile_rows = host_tier ? 64 : 0;
+            // tiles with at most 32 of 64 rows missing are streamed compacted (tools/k2_sparse_probe.py, 28.5 k rows x 4 KiB: 32 % misses
+            // 52.4 -> 55.2 GB/s, 16 %: 47.4 -> 54.6, 8 %: 42.5 -> 52.1, 4 %: 36 -> 47; the 68 % default batch is unchanged, 48 costs it 1 %)
+            h->k2_sparse_max = host_tier ? 32 : 0;
 #ifdef COALA_DEV_KNOBS
             if (const char* e = getenv("COALA_K2_TILE_ROWS")) { int t = atoi(e); if (t == 0 || t == 8 || t == 16 || t == 32 || t == 64) h->k2_tile_rows = t; }
             if (const char* e = getenv("COALA_K2_GRID")) { int g = atoi(e); if (g >= 1 && g <= kStatBlocks) h->k2_grid_cap = g; }
+            if (const char* e = getenv("COALA_K2_SPARSE")) { int g = atoi(e); if (g >= 0 && g <= 64) h->k2_sparse_max = g; }
 #endif
         }
         if (cfg->max_batch) rc = ensure_scratch(h, cfg->max_batch, nullptr);
@@ -1088,8 +1123,8 @@ static int read_feature_impl(coala_cache_t* h, float* out, const int64_t* idx, i
                 ProfScope ps(h, s, 2, 0);
                 const int64_t tiles = ((int64_t)rs.total + tile_rows - 1) / tile_rows;
                 const dim3 grid(grid_for(tiles, 4, h->k2_grid_cap));
-                if (redir) ps.launch(miss_fill_kernel<CD, VEC, true>, grid, dim3(256), d, idx, out, tile_rows, gen, rs, rd);
-                else ps.launch(miss_fill_kernel<CD, VEC, false>, grid, dim3(256), d, idx, out, tile_rows, gen, rs, rd);
+                if (redir) ps.launch(miss_fill_kernel<CD, VEC, true>, grid, dim3(256), d, idx, out, tile_rows, h->k2_sparse_max, gen, rs, rd);
+                else ps.launch(miss_fill_kernel<CD, VEC, false>, grid, dim3(256), d, idx, out, tile_rows, h->k2_sparse_max, gen, rs, rd);
                 return COALA_OK;
             });
         }

@@ -15,9 +15,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # the launch shape of the kernels is a tunable of the DEVELOPMENT library only (read at handle creation): the default for a host
-# cold tier (64-row verdict tiles), one chunk per step as behind an HBM tier, an odd narrow grid with 16-row tiles, one-block grids
+# cold tier (64-row verdict tiles), one chunk per step as behind an HBM tier, an odd narrow grid with 16-row tiles, one-block grids,
+# every tile streamed compacted / none / a low threshold with 32-row tiles
 KNOBS = {2: {"COALA_K2_TILE_ROWS": "0"}, 3: {"COALA_K2_TILE_ROWS": "16", "COALA_K2_GRID": "3"},
-         4: {"COALA_K2_TILE_ROWS": "64", "COALA_K2_GRID": "1", "COALA_K1_GRID": "5"}, 5: {"COALA_K1_WAVES": "4", "COALA_K1_PASSES": "2"}}
+         4: {"COALA_K2_TILE_ROWS": "64", "COALA_K2_GRID": "1", "COALA_K1_GRID": "5"}, 5: {"COALA_K1_WAVES": "4", "COALA_K1_PASSES": "2"},
+         6: {"COALA_K2_SPARSE": "64"}, 7: {"COALA_K2_SPARSE": "0"}, 8: {"COALA_K2_SPARSE": "5", "COALA_K2_TILE_ROWS": "32", "COALA_K2_GRID": "2"}}
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])

@@ -15,4 +15,6 @@ python3 tools/fetch_gap_probe.py 2>&1 | grep -v amdgpu.ids > $O/${ROUND}_prefetc
 (echo "# tools/sampler_fanout_probe.py (MI355X; 10 M-node power-law graph, 1024 seeds; round 1: 0.107 / 0.110 / 0.210 / 0.197 ms for 5,5 / 10,10 / 15,10,5 / 10,10,10)"; python3 tools/sampler_fanout_probe.py 2>&1 | grep -v amdgpu.ids) > $O/${ROUND}_sampler_fanouts.txt; echo "sampler rc=$?"
 python3 tools/backend_compare_probe.py 2>/dev/null | grep "^{" | python3 -m json.tool > $O/${ROUND}_backend_compare.json; echo "backend compare rc=$?"
 for g in community powerlaw; do python3 tools/color_affinity_probe.py --graph $g 2>/dev/null | grep "^{" | python3 -m json.tool > $O/${ROUND}_color_affinity_$g.json; echo "colour $g rc=$?"; done
+(echo "# --- compaction off (K2_SPARSE=0, development build): every tile walked chunk by chunk, the round-1 behaviour"; K2_SPARSE=0 python3 tools/k2_sparse_probe.py 2>&1 | grep "^miss"
+ echo "# --- product (tiles with <= 32 of 64 rows missing are ranked at once and streamed compacted)"; python3 tools/k2_sparse_probe.py 2>&1 | grep "^miss") > $O/${ROUND}_k2_sparse_misses.body; echo "k2 sparse rc=$?"
 ls -la $O

@@ -182,7 +182,9 @@ void orc_dist_fetch(orc_cache** caches, int G, const int64_t* const* idx, const 
         for (int s = 0; s < G; ++s) total += cnt[s][o];
         int64_t* ids = (int64_t*)malloc(sizeof(int64_t) * (total > 0 ? total : 1));
         int dim = (int)caches[o]->dim;
-        float* rows = out ? (float*)malloc(sizeof(float) * (size_t)(total > 0 ? total : 1) * dim) : NULL;
+        int want = 0; /* tag-only callers pass no output arrays: counters and tags only */
+        for (int s = 0; out && s < G; ++s) want |= out[s] != NULL;
+        float* rows = want ? (float*)malloc(sizeof(float) * (size_t)(total > 0 ? total : 1) * dim) : NULL;
         int64_t off = 0;
         for (int s = 0; s < G; ++s) { memcpy(ids + off, node[s] + max_n * o, sizeof(int64_t) * cnt[s][o]); off += cnt[s][o]; }
         orc_read_feature(caches[o], ids, total, rows, schedule); /* cache_kernel.cu:93-111 with the distributed set index */

@@ -45,6 +45,8 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--cache-mb", type=int, default=4096)
     ap.add_argument("--avg-degree", type=float, default=12.0)
+    ap.add_argument("--rounds", type=int, default=0, help="N>1: row-exchange rounds per fetch (1..8); default: measured during the warm-up")
+    ap.add_argument("--no-tune-rounds", action="store_true", help="N>1: keep the default number of exchange rounds (2) instead of measuring")
     ap.add_argument("--prewarm", type=int, default=400, help="untimed minibatches that bring the cache to steady state")
     ap.add_argument("--backend", type=str, default=None, help="isolated | nccl | nvshmem (default: isolated at N=1, nccl otherwise)")
     ap.add_argument("--mode", type=str, default="minibatch", choices=["minibatch", "allhit", "allmiss"],
@@ -352,6 +354,23 @@ def _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, dev
         manager.fetch_feature(ids_for(s))
     torch.cuda.synchronize()
     log(f"prewarm {args.prewarm} minibatches in {time.time() - t0:.1f}s")
+    # N>1: how many rounds the row exchange is cut into (cold fill of slice k+1 beside the rows of slice k) is decided by
+    # measurement on the machine at hand, untimed, on minibatches of their own; every rank ends with the same setting
+    rounds_probe = None
+    if world > 1 and manager.exchange is not None and hasattr(manager.exchange, "rounds"):
+        if args.rounds:
+            manager.exchange.rounds = args.rounds
+            rounds_probe = {"chosen": args.rounds, "how": "--rounds"}
+        elif args.mode == "minibatch" and not args.no_tune_rounds:
+            t0 = time.time()
+            tune = [ids_for(total_steps + s) for s in range(72)]
+            best, probe = manager.tune_exchange_rounds(tune, candidates=(1, 2, 4))
+            del tune
+            rounds_probe = {"chosen": best, "how": "measured: 24 minibatches per setting in alternating blocks of 8, slowest rank", "ms_per_fetch": probe}
+            log(f"exchange rounds: {probe} -> {best} ({time.time() - t0:.1f}s)")
+        else:
+            rounds_probe = {"chosen": manager.exchange.rounds, "how": "default"}
+        os.environ["COALA_EXCHANGE_ROUNDS"] = str(rounds_probe["chosen"])   # the managers of the later legs follow
     batches = [ids_for(args.prewarm + s) for s in range(args.warmup + args.steps)]  # resident in HBM before timing
     torch.cuda.synchronize()
 
@@ -512,6 +531,7 @@ def _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, dev
                        "exchange_transport": (exchange_note or getattr(manager, "exchange_kind", None)) if world > 1 else None,
                        "rccl_ranks": (getattr(manager.exchange, "rccl_ranks", None) or
                                       (dist.get_world_size(comm.nccl_cache_gather) if not single_dev else None)) if world > 1 else None,
+                       "exchange_rounds": rounds_probe,
                        "input_nodes": "bucketed by owner by the sampler (no routing pass, rows received in place)" if bucket else "sampler order",
                        "parity_check": "rows of one warm-up minibatch == synthetic table formula, bit-exact, on every rank", "cold_tier": "HBM" if args.cold_tier == "hbm" else ("pinned host, owner-partitioned" if cold_partitioned else "pinned host"),
                        "prewarm_steps": args.prewarm, "rows_scale_factor": rows_scale,

@@ -63,7 +63,7 @@ class AllToAllExchange(object):
     un-permute per round.  `ops` provides the device primitives as pointer-level calls: a COALA_GNN_Pybind cache object in
     the product; tests may inject another provider to exercise this host logic with gloo on CPU tensors."""
 
-    def __init__(self, group, rank, world, dim, device, stage_through_host=None, rounds=2):
+    def __init__(self, group, rank, world, dim, device, stage_through_host=None, rounds=None):
         self.group, self.rank, self.world, self.dim, self.device = group, rank, world, dim, device
         # RCCL moves GPU tensors directly.  A gloo group cannot (no CUDA all-to-all): then the buffers are staged through
         # host memory -- transport only, used by the multi-process tests on a one-GPU box; the kernels stay on the GPU.
@@ -71,7 +71,10 @@ class AllToAllExchange(object):
         if stage_through_host is None:
             stage_through_host = (world > 1 and on_gpu and dist.is_initialized() and dist.get_backend(group) == "gloo")
         self.stage_through_host = bool(stage_through_host)
-        self.rounds = max(1, int(rounds))
+        if rounds is None:  # the same default and the same switch as the native call (coala_comm.cpp)
+            import os
+            rounds = os.environ.get("COALA_EXCHANGE_ROUNDS", "2")
+        self.rounds = min(max(1, int(rounds)), 8)
         self._pending = None
         self.counts = torch.zeros(world, dtype=torch.int64, device=device)
         self.offsets = torch.zeros(world + 1, dtype=torch.int64, device=device)
@@ -294,6 +297,14 @@ class NativeExchange(object):
         self.last_send_counts = self.last_recv_counts = None
         self._profile = False
 
+    @property
+    def rounds(self):
+        return int(self._lib.coala_comm_get_rounds(self._h))
+
+    @rounds.setter
+    def rounds(self, k):  # must be set to the same value on every rank, between fetches
+        self._capi.check(self._lib.coala_comm_set_rounds(self._h, int(k)))
+
     # same profiling surface as AllToAllExchange (bench.py's xGMI figure)
     @property
     def profile(self):
@@ -482,6 +493,51 @@ class COALA_GNN_Manager(object):
             if len(self._agg_events) >= 64:
                 self._fold_events(wait=False)
         return (*batch, return_torch)
+
+    def tune_exchange_rounds(self, batches, candidates=(1, 2, 4), reps=None):
+        """Pick the number of row-exchange rounds per fetch by measurement: how far the cold fill (PCIe) and the row exchange (xGMI)
+        overlap depends on the miss ratio and on the link rates of the machine at hand.  Collective over the cache group: every
+        rank passes equally many batches (each is fetched once -- the delivered rows do not depend on the setting), the slowest
+        rank's time per setting decides, every rank ends with the same choice.  -> (chosen, {rounds: ms per fetch})"""
+        xch = self.exchange
+        G = self.MPI_comm_manager.local_size
+        if xch is None or G <= 1 or not hasattr(xch, "rounds"):
+            return None, {}
+        cands = [int(k) for k in candidates]
+        reps = int(reps) if reps else len(batches) // len(cands)
+        if reps < 1 or reps * len(cands) > len(batches):
+            raise ValueError(f"{len(cands)} settings x {max(reps, 1)} fetches need more than {len(batches)} batches")
+        # the settings take turns in short blocks (A B C A B C ...): the cache state and the batch sizes drift along the sequence
+        block = max(1, reps // 3)
+        keep_sync, self.sync_on_return = self.sync_on_return, False
+        grp = self.MPI_comm_manager.local_gloo_gather
+        ms = torch.zeros(len(cands), dtype=torch.float64)
+        done = [0] * len(cands)
+        pos, turn = 0, 0
+        try:
+            while min(done) < reps:
+                j = turn % len(cands)
+                turn += 1
+                take = min(block, reps - done[j])
+                if take <= 0:
+                    continue
+                xch.rounds = cands[j]
+                dist.barrier(group=grp)
+                torch.cuda.current_stream().synchronize()
+                t0 = time.perf_counter()
+                for b in batches[pos: pos + take]:
+                    self.fetch_feature(b)
+                torch.cuda.current_stream().synchronize()
+                ms[j] += (time.perf_counter() - t0) * 1e3
+                done[j] += take
+                pos += take
+            ms /= reps
+            dist.all_reduce(ms, op=dist.ReduceOp.MAX, group=grp)
+        finally:
+            self.sync_on_return = keep_sync
+        best = cands[int(torch.argmin(ms))]
+        xch.rounds = best
+        return best, {k: round(float(t), 4) for k, t in zip(cands, ms)}
 
     def _fold_events(self, wait):
         """Move finished (start, end) event pairs into the aggregation timer; with wait=True, all of them."""

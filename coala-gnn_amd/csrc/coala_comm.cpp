@@ -397,6 +397,8 @@ int coala_comm_set_rounds(coala_comm_t* c, int rounds) {
     return COALA_OK;
 }
 
+int coala_comm_get_rounds(const coala_comm_t* c) { return c ? c->rounds : 0; }
+
 int coala_comm_last_counts(const coala_comm_t* c, int64_t* send, int64_t* recv) {
     if (!c) return fail(COALA_EINVAL, "null communicator");
     for (int p = 0; p < c->nranks; ++p) {

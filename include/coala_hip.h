@@ -176,6 +176,7 @@ int coala_comm_create_inproc(coala_comm_group_t* g, int rank, int device, coala_
 /* Row-exchange rounds per fetch, 1..8 (default 2, or COALA_EXCHANGE_ROUNDS): round k ships the k-th slice of every peer's
  * segment while the cold fill of slice k+1 runs.  Must be the same on every rank. */
 int coala_comm_set_rounds(coala_comm_t* c, int rounds);
+int coala_comm_get_rounds(const coala_comm_t* c); /* 0 for a null handle */
 /* per-peer id counts of the last fetch (host int64[nranks] each, either may be NULL) */
 int coala_comm_last_counts(const coala_comm_t* c, int64_t* send, int64_t* recv);
 /* out[i, 0:dim] = row of idx[i], wherever its owner (idx[i] % nranks) is.  Collective: every rank of the communicator calls

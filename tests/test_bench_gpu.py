@@ -62,6 +62,8 @@ def test_bench_two_ranks_on_one_gpu_with_epoch_leg():
     x = d["config_fanout_10_10"]
     assert "error" not in x and x["value"] > 0 and x["steps"] == 60 and 0 <= x["hit_ratio"] <= 1
     assert d["config"]["exchange_transport"] == "torch" and "parity_check" in d["config"]   # gloo hook: no RCCL group -> torch transport
+    rp = d["config"]["exchange_rounds"]         # measured during the warm-up, the same choice on every rank
+    assert rp["chosen"] in (1, 2, 4) and set(rp["ms_per_fetch"]) == {"1", "2", "4"} and all(v > 0 for v in rp["ms_per_fetch"].values())
 
 
 def test_bench_rank_failure_is_visible():

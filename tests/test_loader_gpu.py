@@ -258,3 +258,45 @@ def test_shm_creator_never_reuses_a_stale_segment(hiplib):
     assert not buf.any()
     mgr.cleanup()
     assert not os.path.exists("/dev/shm" + name)
+
+
+@pytest.mark.parametrize("steps", [1, 2, 3])
+def test_pipelined_loader_short_epochs(hiplib, oracle, tmp_path, steps):
+    """Epochs shorter than the depth of the default loader's pipeline (sample two steps ahead, fetch one ahead), two epochs in a
+    row: the same batches as the blocking loader, StopIteration exactly after `steps` items, and the second epoch starts clean."""
+    import torch
+    from COALA_GNN import COALA_GNN_DataLoader, MPI_Comm_Manager, Node_Distributor, SSD_INFO
+    from COALA_GNN.sampler import NeighborSampler
+    from COALA_GNN.synthetic import alloc_pinned_table, block_colors, feature_rows_torch, powerlaw_csc
+    n_nodes, dim, batch, fan = 8000, 64, 32, [3, 3]
+    table = alloc_pinned_table(n_nodes, dim, seed=2, device=0)
+    indptr, indices = powerlaw_csc(n_nodes, 6.0, seed=5, device="cuda")
+    color, tk, sc, ncol = block_colors(n_nodes, nodes_per_color=256)
+    files = ColorFiles(tmp_path, color, tk, sc)
+    comm = MPI_Comm_Manager(0)
+    comm.initialize_nested_process_group("isolated")
+    train_ids = torch.randperm(int(0.6 * n_nodes), generator=torch.Generator().manual_seed(4))[:batch * (steps + 1)]
+    seen = {}
+    for name, kw in (("blocking", {"sync_fetch": True}), ("pipelined", {})):
+        nd = Node_Distributor(comm, train_ids, batch, files.color_file, files.topk_file, files.score_file, parsing_method="baseline")
+        sampler = NeighborSampler(fan, seed=1)
+        g = sampler.make_graph(indptr, indices)
+        loader = COALA_GNN_DataLoader(SSD_INFO(1, dim * 4, 1024, 0), nd, g, sampler, batch, dim, fan, 1, "cuda:0", refresh_counter=2,
+                                      cache_backend="isolated", sim_buf=table, num_rows=n_nodes, **kw)
+        assert len(loader) == steps
+        got = []
+        for epoch in range(2):
+            n = 0
+            for input_nodes, seeds, blocks, feat in loader:
+                assert torch.equal(feat, feature_rows_torch(input_nodes, dim, 2))
+                got.append((epoch, input_nodes.clone(), seeds.clone()))
+                n += 1
+            assert n == steps
+        torch.cuda.synchronize()
+        seen[name] = (got, loader.COALA_GNN_Manager.COALA_GNN_Cache.stats())
+        del loader, nd
+    a, b = seen["blocking"], seen["pipelined"]
+    assert a[1] == b[1] and len(a[0]) == len(b[0]) == 2 * steps
+    for (ea, ia, sa), (eb, ib, sb) in zip(a[0], b[0]):
+        assert ea == eb and torch.equal(ia, ib) and torch.equal(sa, sb)
+    table.close()

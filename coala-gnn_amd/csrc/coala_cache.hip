@@ -719,6 +719,11 @@ struct coala_cache {
     std::vector<hipEvent_t> ev_pool;
     coala_cache_profile_t prof{};
     hipStream_t last_stream = nullptr;    // stream of the last bracketed launch (for the empty-bracket calibration)
+    // The handle's tables and scratch are ordered by the stream its calls are enqueued on.  A caller that moves to another stream
+    // keeps that order: the new stream first waits for what the handle enqueued last on the old one (follow_stream).
+    hipStream_t order_stream = nullptr;
+    bool order_set = false;
+    hipEvent_t order_ev = nullptr;
     uint64_t table_bytes = 0;
     int k2_grid_cap = kStatBlocks;        // K2 blocks: 16 when the cold tier is host memory.  The link, not the chip, is the limit, and
                                           // what matters is the bytes of PCIe reads in flight (blocks x 4 waves x 16 KB): ~1 MB
@@ -751,6 +756,18 @@ namespace {
 
 #define fail coala_fail_
 #define HIPCHK COALA_HIPCHK
+
+int follow_stream(coala_cache* h, hipStream_t s) {
+    if (h->order_set && h->order_stream != s) {
+        if (!h->order_ev) HIPCHK(hipEventCreateWithFlags(&h->order_ev, hipEventDisableTiming));
+        // (a stream the caller has destroyed in the meantime has nothing left to wait for)
+        if (hipEventRecord(h->order_ev, h->order_stream) == hipSuccess) HIPCHK(hipStreamWaitEvent(s, h->order_ev, 0));
+        else (void)hipGetLastError();
+    }
+    h->order_stream = s;
+    h->order_set = true;
+    return COALA_OK;
+}
 
 int ilog2_exact(uint64_t v) {
     if (v == 0 || (v & (v - 1))) return -1;
@@ -1003,6 +1020,7 @@ int coala_cache_destroy(coala_cache_t* h) {
     if (h->color_pin) (void)hipHostFree(h->color_pin);
     if (h->color_pin_async) (void)hipHostFree(h->color_pin_async);
     if (h->color_ev) (void)hipEventDestroy(h->color_ev);
+    if (h->order_ev) (void)hipEventDestroy(h->order_ev);
     delete h;
     return COALA_OK;
 }
@@ -1073,6 +1091,7 @@ static int read_feature_impl(coala_cache_t* h, float* out, const int64_t* idx, i
     }
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipSetDevice(h->cfg.device));
+    if (int rc_ = follow_stream(h, s)) return rc_;
     int rc = ensure_scratch(h, (uint64_t)n, s);
     if (rc) return rc;
     if (phases & kPhaseProbe) {
@@ -1192,6 +1211,7 @@ int coala_cache_route(coala_cache_t* h, const int64_t* idx, int64_t n, int n_par
     if (bucket_stride < 0) return fail(COALA_EINVAL, "negative bucket_stride");
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipSetDevice(h->cfg.device));
+    if (int rc_ = follow_stream(h, s)) return rc_;
     const int64_t n_tiles = (n + kRouteTile - 1) / kRouteTile;
     const uint64_t need = (uint64_t)(n_tiles > 0 ? n_tiles : 1) * (uint64_t)n_parts;
     if (need > h->wave_counts_cap) {
@@ -1280,6 +1300,7 @@ int coala_cache_color_counts(coala_cache_t* h, int32_t* dst, int32_t n_entries, 
     if (!h->d.color_counters) { memset(dst, 0, (size_t)n_entries * 4); return COALA_OK; }
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipSetDevice(h->cfg.device));
+    if (int rc_ = follow_stream(h, s)) return rc_;
     // staged through pinned memory owned by the handle: a D2H copy into pageable memory waits for every queue of the device
     // (measured: 11 ms per call when a prefetching loader had run ahead), this one only for `stream`
     if (!h->color_pin) HIPCHK(hipHostMalloc((void**)&h->color_pin, ((size_t)h->cfg.num_colors + 1) * 4, hipHostMallocDefault));
@@ -1298,6 +1319,7 @@ int coala_cache_color_counts_async(coala_cache_t* h, int32_t n_entries, void* st
     if (n_entries < 0 || n_entries > h->cfg.num_colors + 1) return fail(COALA_EINVAL, "n_entries=%d exceeds num_colors+1=%d", n_entries, h->cfg.num_colors + 1);
     if (h->color_pending >= 0) return fail(COALA_EINVAL, "a colour-counter snapshot is already pending: call coala_cache_color_counts_finish first");
     HIPCHK(hipSetDevice(h->cfg.device));
+    if (int rc_ = follow_stream(h, (hipStream_t)stream)) return rc_;
     if (h->d.color_counters) {
         if (!h->color_pin_async) HIPCHK(hipHostMalloc((void**)&h->color_pin_async, ((size_t)h->cfg.num_colors + 1) * 4, hipHostMallocDefault));
         if (!h->color_ev) HIPCHK(hipEventCreateWithFlags(&h->color_ev, hipEventDisableTiming));
@@ -1339,6 +1361,7 @@ static int read_stats(coala_cache_t* h, hipStream_t s, uint64_t* hit, uint64_t* 
 int coala_cache_stats(coala_cache_t* h, uint64_t* hit, uint64_t* miss, uint64_t* range_errors, int reset, void* stream) {
     if (!h) return fail(COALA_EINVAL, "null handle");
     HIPCHK(hipSetDevice(h->cfg.device));
+    if (int rc_ = follow_stream(h, (hipStream_t)stream)) return rc_;
     uint64_t v0, v1, v2;
     int rc = read_stats(h, (hipStream_t)stream, &v0, &v1, &v2, reset != 0);
     if (rc) return rc;
@@ -1352,6 +1375,7 @@ int coala_cache_dump(coala_cache_t* h, uint64_t* keys, uint32_t* set_cnt, uint32
     if (!h) return fail(COALA_EINVAL, "null handle");
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipSetDevice(h->cfg.device));
+    if (int rc_ = follow_stream(h, (hipStream_t)stream)) return rc_;
     const uint64_t slots = h->d.num_sets * COALA_WAYS;
     HIPCHK(hipStreamSynchronize(s));
     if (keys) HIPCHK(hipMemcpy(keys, h->d.keys, slots * 8, hipMemcpyDeviceToHost));

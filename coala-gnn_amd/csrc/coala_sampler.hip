@@ -440,6 +440,7 @@ struct coala_sampler {
     int ring_layers[kRing] = {};
     int ring_parts[kRing] = {};
     uint64_t calls = 0;
+    hipStream_t last_stream = nullptr; // stream of the previous call
 };
 
 namespace {
@@ -557,6 +558,10 @@ int coala_sampler_sample(coala_sampler_t* s, const int64_t* seeds, int64_t n_see
     if (n_parts > 0 && (!bucketing->bucketed_nodes || !bucketing->counts || !bucketing->dst_in_src)) return fail(COALA_EINVAL, "bucketing: null buffer");
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipSetDevice(s->device));
+    // the handle's scratch (hash table, scan state) is ordered by the stream of its calls: a caller that moves to another stream
+    // first waits there for the previous call's last kernel
+    if (s->calls > 0 && s->last_stream != st) HIPCHK(hipStreamWaitEvent(st, s->done[(s->calls - 1) % kRing], 0));
+    s->last_stream = st;
     // capacities: layer l has at most cap_l dst nodes and cap_l*(f_l+1) source nodes
     int64_t cap = n_seeds;
     uint64_t max_items = 0, max_nbr = 0;

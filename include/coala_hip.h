@@ -9,7 +9,9 @@
  * Streams: `stream` is a hipStream_t passed as void*.  Work is enqueued on it and the call returns without
  * synchronising, unless the handle was created with COALA_FLAG_SYNC (the reference's behaviour: every native call
  * ends in cudaDeviceSynchronize, COALA_GNN_Modules/ssd_gnn_cache.cuh:266) in which case the call returns after the
- * stream has drained.
+ * stream has drained.  A cache or sampler handle keeps its own work in program order across streams: a call on another
+ * stream than the handle's previous call first waits there (hipStreamWaitEvent, no host wait) for that call's work.  One handle
+ * is driven by one host thread at a time.
  */
 #ifndef COALA_HIP_H
 #define COALA_HIP_H

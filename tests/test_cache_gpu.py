@@ -304,3 +304,35 @@ def test_full_size_big_configs_properties(hiplib, oracle, torch_cuda, name, dim,
     assert orc.hit_cnt > 0.99 * n  # second pass: (almost) everything was kept (a set overflows only past 32 ids)
     cache.close()
     table.close()
+
+
+def test_calls_that_change_streams_keep_their_order(hiplib, torch_cuda):
+    """A cache handle's tables and scratch are ordered by the stream of its calls; a caller that moves to another (non-blocking)
+    stream without synchronising still gets them in program order: the second batch -- the same ids on another stream, right behind
+    a 36,864-row cold fill -- must see every line of the first (all hits), the stats read on a third stream both batches."""
+    torch = torch_cuda
+    P = hiplib
+    from COALA_GNN.synthetic import alloc_pinned_table, feature_rows_torch
+    dim, num_rows, n = 1024, 1 << 20, 36864
+    table = alloc_pinned_table(num_rows, dim, seed=5, device=0)
+    ctrl = P.SSD_GNN_SSD_Controllers(1, 4096, 1024, 0, 0, dim, True)
+    cache = P.Isolated_Cache(ctrl, None, 0, 1, 4096, table.device_ptr, num_rows=num_rows, sync=False)
+    ids = torch.randperm(num_rows, generator=torch.Generator().manual_seed(2))[:n].cuda()
+    outs = [torch.empty((n, dim), dtype=torch.float32, device="cuda") for _ in range(2)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    for rounds in range(3):
+        cache.stats(reset=True)
+        fresh = (ids + 1 + rounds) % num_rows if rounds else ids
+        with torch.cuda.stream(streams[0]):
+            cache.read_feature(outs[0].data_ptr(), fresh.data_ptr(), n)      # ~1.4 ms of PCIe fill (first round: all misses)
+        with torch.cuda.stream(streams[1]):
+            cache.read_feature(outs[1].data_ptr(), fresh.data_ptr(), n)      # enqueued at once on another stream
+        with torch.cuda.stream(streams[2]):
+            hit, miss, bad = cache.stats()
+        torch.cuda.synchronize()
+        assert hit >= n and hit + miss == 2 * n and bad == 0, (rounds, hit, miss)
+        want = feature_rows_torch(fresh, dim, 5)
+        assert torch.equal(outs[0], want) and torch.equal(outs[1], want)
+    cache.close()
+    table.close()

@@ -206,3 +206,31 @@ def test_native_mean_aggregate_matches_torch(hiplib, dim, fan):
         feat = torch.rand(b.num_src, dim, device="cuda")
         assert not b.mean_aggregate(feat).requires_grad
     g.close()
+
+
+def test_sampler_calls_that_change_streams_keep_their_order(hiplib, oracle):
+    """The sampler handle's hash table and scan state are ordered by the stream of its calls; calls that alternate between two
+    non-blocking streams without any synchronisation in between still equal the CPU twin, call by call."""
+    import torch
+    from COALA_GNN.sampler import NeighborSampler
+    from COALA_GNN.synthetic import powerlaw_csc
+    n_nodes = 200_000
+    indptr, indices = powerlaw_csc(n_nodes, 10.0, seed=3, device="cuda")
+    smp = NeighborSampler([10, 10], seed=5)
+    g = smp.make_graph(indptr, indices)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    seeds = [torch.randperm(n_nodes, generator=torch.Generator().manual_seed(s))[:1024].cuda() for s in range(12)]
+    torch.cuda.synchronize()
+    outs = []
+    for lo in (0, 6):  # at most 8 calls may be outstanding: two groups of 6, nothing but the event waits of sample_end in between
+        pend = []
+        for i in range(lo, lo + 6):
+            with torch.cuda.stream(streams[i % 2]):
+                pend.append(smp.sample_begin(g, seeds[i], step=i))
+        outs += [smp.sample_end(p) for p in pend]
+    torch.cuda.synchronize()
+    ip, ix = indptr.cpu().numpy(), indices.cpu().numpy()
+    for i, (input_nodes, _, blocks) in enumerate(outs):
+        want = oracle.sample_blocks(ip, ix, seeds[i].cpu().numpy(), [10, 10], 5, i)
+        assert np.array_equal(input_nodes.cpu().numpy(), want[-1][0]), f"call {i}"
+    g.close()

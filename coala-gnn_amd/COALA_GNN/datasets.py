@@ -1,7 +1,12 @@
 """On-disk formats of the reference's shared-CSC datasets: csc_indptr.npy / csc_indices.npy /
 csc_edge_ids.npy, node_feat.npy, node_label_*.npy, 60/20/20 masks -- examples/ssd_gnn_dataloader.py:401-563 (IGB),
 :687-854 (OGB).  The feature table goes to a pinned cold tier (shared POSIX shm across the local ranks, or private), the
-CSC arrays to HBM.  No dataset ships with the GPU box; tests write small .npy files in the same layout."""
+CSC arrays to HBM.  No dataset ships with the GPU box; tests write small .npy files in the same layout.
+
+The reference makes the csc_*.npy files from the datasets' edge_index.npy with DGL (examples/create_csc_graph.py:255-304:
+dgl.graph((src, dst)).formats('csc').adj_tensors('csc')); DGL does not exist here, so csc_from_edge_index does the conversion on the
+GPU (one stable radix sort by destination: the whole of IGB-large's 1.2 G edges fits the 288 GB of one MI355X), tools/create_csc_graph.py
+writes the three files where the reference puts them, and SharedCSCDataset falls back to edge_index.npy when they are missing."""
 import os
 
 import numpy as np
@@ -10,7 +15,46 @@ import torch
 from .Shared_Tensor import Shared_UVA_Tensor_Manager
 from .sampler import CSCGraph
 
-__all__ = ["SharedCSCDataset"]
+__all__ = ["SharedCSCDataset", "csc_from_edge_index", "split_edge_index"]
+
+
+def split_edge_index(edge_index):
+    """edge_index.npy as the datasets ship it -> (src, dst) views: [E, 2] rows of (src, dst) for IGB (create_csc_graph.py:274),
+    [2, E] for OGB (:295)."""
+    if edge_index.ndim != 2 or 2 not in edge_index.shape:
+        raise ValueError(f"edge_index must be [E, 2] or [2, E], got {tuple(edge_index.shape)}")
+    if edge_index.shape[1] == 2:
+        return edge_index[:, 0], edge_index[:, 1]
+    return edge_index[0], edge_index[1]
+
+
+def csc_from_edge_index(src, dst, num_nodes, device=None):
+    """Edge list -> CSC by destination, what dgl.graph((src, dst)).adj_tensors('csc') gives the reference: indptr int64 [N + 1] over
+    destination nodes, indices int64 [E] = the sources of each column, edge_ids int64 [E] = the position of each entry in the
+    edge list.  Entries of a column keep the order of the edge list (one STABLE sort by destination; DGL documents no order
+    within a column, and it is not installed here to compare: the sampler draws positions of a column, so its samples follow
+    this order).  Runs wherever the tensors are (`device` moves them first): on the GPU it is one radix sort of E keys."""
+    src = torch.as_tensor(src)
+    dst = torch.as_tensor(dst)
+    if device is not None:
+        src, dst = src.to(device), dst.to(device)
+    src, dst = src.to(torch.int64).contiguous().view(-1), dst.to(torch.int64).contiguous().view(-1)
+    n = int(num_nodes)
+    if src.numel() != dst.numel():
+        raise ValueError("src and dst differ in length")
+    if src.numel():
+        lo = int(torch.minimum(src.min(), dst.min()))
+        hi = int(torch.maximum(src.max(), dst.max()))
+        if lo < 0 or hi >= n:
+            raise ValueError(f"node ids span [{lo}, {hi}] but the graph has {n} nodes")
+    key = dst.to(torch.int32) if n <= 0x7FFFFFFF else dst   # halves the sort's working set for every published dataset
+    edge_ids = torch.sort(key, stable=True).indices
+    del key
+    indices = src[edge_ids]
+    indptr = torch.zeros(n + 1, dtype=torch.int64, device=dst.device)
+    if dst.numel():
+        torch.cumsum(torch.bincount(dst, minlength=n), 0, out=indptr[1:])
+    return indptr, indices, edge_ids
 
 
 class SharedCSCDataset(object):
@@ -33,8 +77,13 @@ class SharedCSCDataset(object):
             for lo in range(0, self.num_nodes, step):
                 host[lo: lo + step] = feat_mm[lo: lo + step]
         comm_manager.local_comm.Barrier()
-        indptr = torch.from_numpy(np.load(os.path.join(root, "csc_indptr.npy")).astype(np.int64, copy=False))   # :496-515
-        indices = torch.from_numpy(np.load(os.path.join(root, "csc_indices.npy")).astype(np.int64, copy=False))
+        if os.path.exists(os.path.join(root, "csc_indptr.npy")):
+            indptr = torch.from_numpy(np.load(os.path.join(root, "csc_indptr.npy")).astype(np.int64, copy=False))   # :496-515
+            indices = torch.from_numpy(np.load(os.path.join(root, "csc_indices.npy")).astype(np.int64, copy=False))
+        else:  # no preprocessed CSC: convert the dataset's own edge list on the GPU (the reference's DGL path, :288-319)
+            e_src, e_dst = split_edge_index(np.load(os.path.join(root, "edge_index.npy"), mmap_mode="r"))
+            indptr, indices, _ = csc_from_edge_index(torch.from_numpy(np.ascontiguousarray(e_src)), torch.from_numpy(np.ascontiguousarray(e_dst)),
+                                                     self.num_nodes, device=device)
         labels_path = os.path.join(root, f"node_label_{num_classes}.npy")
         labels = torch.from_numpy(np.load(labels_path).astype(np.int64)) if os.path.exists(labels_path) else torch.zeros(self.num_nodes, dtype=torch.int64)
         n_train, n_val = int(self.num_nodes * 0.6), int(self.num_nodes * 0.2)        # :550-559

@@ -1,0 +1,71 @@
+"""Edge list -> CSC (COALA_GNN.datasets.csc_from_edge_index; the reference does it with DGL, examples/create_csc_graph.py:274-286):
+host logic on CPU tensors against a numpy restatement (stable argsort by destination)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _want(src, dst, n):
+    perm = np.argsort(dst, kind="stable")
+    indptr = np.concatenate([[0], np.cumsum(np.bincount(dst, minlength=n))]).astype(np.int64)
+    return indptr, src[perm], perm
+
+
+@pytest.mark.parametrize("n,e,seed", [(1, 0, 0), (5, 0, 1), (7, 40, 2), (1000, 20000, 3), (50000, 200000, 4)])
+def test_csc_from_edge_index_matches_stable_sort(n, e, seed):
+    from COALA_GNN.datasets import csc_from_edge_index
+    rng = np.random.default_rng(seed)
+    src = rng.integers(0, n, size=e).astype(np.int64)          # duplicates, self loops and isolated nodes all occur
+    dst = rng.integers(0, max(n // 2, 1), size=e).astype(np.int64)
+    indptr, indices, eids = csc_from_edge_index(torch.from_numpy(src), torch.from_numpy(dst), n)
+    w = _want(src, dst, n)
+    assert indptr.dtype == indices.dtype == eids.dtype == torch.int64
+    assert np.array_equal(indptr.numpy(), w[0]) and np.array_equal(indices.numpy(), w[1]) and np.array_equal(eids.numpy(), w[2])
+    # the properties a CSC must have whatever the order inside a column
+    assert indptr[0] == 0 and indptr[-1] == e and bool((indptr[1:] >= indptr[:-1]).all())
+    assert np.array_equal(dst[eids.numpy()], np.repeat(np.arange(n), np.diff(indptr.numpy())))
+
+
+def test_csc_from_edge_index_rejects_bad_input():
+    from COALA_GNN.datasets import csc_from_edge_index, split_edge_index
+    with pytest.raises(ValueError):
+        csc_from_edge_index(torch.tensor([0, 5]), torch.tensor([1, 2]), 5)       # source id == num_nodes
+    with pytest.raises(ValueError):
+        csc_from_edge_index(torch.tensor([0, 1]), torch.tensor([-1, 2]), 5)
+    with pytest.raises(ValueError):
+        csc_from_edge_index(torch.tensor([0, 1, 2]), torch.tensor([1, 2]), 5)
+    with pytest.raises(ValueError):
+        split_edge_index(np.zeros((3, 3), dtype=np.int64))
+    a = np.arange(12, dtype=np.int64).reshape(6, 2)
+    s, d = split_edge_index(a)                   # IGB layout: rows of (src, dst)
+    assert np.array_equal(s, a[:, 0]) and np.array_equal(d, a[:, 1])
+    s, d = split_edge_index(a.T.copy())          # OGB layout: [2, E]
+    assert np.array_equal(s, a[:, 0]) and np.array_equal(d, a[:, 1])
+
+
+@pytest.mark.parametrize("layout", ["IGB", "OGB"])
+def test_create_csc_graph_tool_writes_the_reference_files(tmp_path, layout):
+    rng = np.random.default_rng(5)
+    n, e = 100000, 30000
+    edges = np.stack([rng.integers(0, n, size=e), rng.integers(0, n, size=e)], axis=1).astype(np.int64)
+    if layout == "IGB":
+        d = tmp_path / "experimental" / "processed" / "paper__cites__paper"
+        d.mkdir(parents=True)
+        np.save(d / "edge_index.npy", edges)
+        cmd = ["--data", "IGB", "--path", str(tmp_path), "--dataset_size", "experimental"]
+    else:
+        d = tmp_path / "x"
+        d.mkdir()
+        np.save(d / "edge_index.npy", edges.T.copy())
+        cmd = ["--edge_index", str(d / "edge_index.npy"), "--num_nodes", str(n)]
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "create_csc_graph.py"), *cmd, "--device", "cpu"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-1000:] + out.stderr[-2000:]
+    w = _want(edges[:, 0], edges[:, 1], n)
+    for name, want in zip(("csc_indptr.npy", "csc_indices.npy", "csc_edge_ids.npy"), w):
+        assert np.array_equal(np.load(d / name), want), name

@@ -300,3 +300,39 @@ def test_pipelined_loader_short_epochs(hiplib, oracle, tmp_path, steps):
     for (ea, ia, sa), (eb, ib, sb) in zip(a[0], b[0]):
         assert ea == eb and torch.equal(ia, ib) and torch.equal(sa, sb)
     table.close()
+
+
+def test_shared_csc_dataset_from_edge_index(hiplib, oracle, tmp_path):
+    """Row f-4: a dataset directory that only holds the edge list (edge_index.npy, IGB layout) -- the conversion the reference does
+    with DGL runs on the GPU when the dataset is opened; same graph as from the preprocessed csc_*.npy files.  Then the
+    conversion alone at 60 M edges on the GPU: a valid CSC whose columns keep the order of the edge list."""
+    import torch
+    from COALA_GNN import MPI_Comm_Manager
+    from COALA_GNN.datasets import SharedCSCDataset, csc_from_edge_index
+    rng = np.random.default_rng(1)
+    n, e, dim = 4000, 30000, 32
+    src = rng.integers(0, n, size=e).astype(np.int64)
+    dst = rng.integers(0, n, size=e).astype(np.int64)
+    feat = oracle.make_features(n, dim, seed=2)
+    np.save(tmp_path / "edge_index.npy", np.stack([src, dst], axis=1))
+    np.save(tmp_path / "node_feat.npy", feat)
+    comm = MPI_Comm_Manager(0)
+    comm.initialize_nested_process_group("isolated")
+    ds = SharedCSCDataset(str(tmp_path), comm, "cuda:0", shm_name=f"/coala_ds_edges_{os.getpid()}")
+    g = ds[0]
+    perm = np.argsort(dst, kind="stable")
+    assert (g.num_nodes, g.num_edges) == (n, e)
+    assert np.array_equal(g.indptr.cpu().numpy(), np.concatenate([[0], np.cumsum(np.bincount(dst, minlength=n))]))
+    assert np.array_equal(g.indices.cpu().numpy(), src[perm])
+    ds.close()
+    # the conversion at size, on the GPU
+    N, E = 10_000_000, 60_000_000
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    s = torch.randint(0, N, (E,), generator=gen, device="cuda")
+    d = torch.randint(0, N, (E,), generator=gen, device="cuda")
+    indptr, indices, eids = csc_from_edge_index(s, d, N)
+    assert int(indptr[0]) == 0 and int(indptr[-1]) == E and bool((indptr[1:] >= indptr[:-1]).all())
+    col = torch.repeat_interleave(torch.arange(N, device="cuda"), indptr[1:] - indptr[:-1])
+    assert torch.equal(d[eids], col) and torch.equal(s[eids], indices)
+    same_col = col[1:] == col[:-1]
+    assert bool((eids[1:][same_col] > eids[:-1][same_col]).all())   # inside a column: the order of the edge list

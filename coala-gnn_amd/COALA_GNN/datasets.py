@@ -57,14 +57,34 @@ def csc_from_edge_index(src, dst, num_nodes, device=None):
     return indptr, indices, edge_ids
 
 
+def _layout_paths(root, layout, dataset_size, num_classes):
+    """Where the reference's loaders look for each file (examples/ssd_gnn_dataloader.py)."""
+    if layout == "IGB":     # IGBDatast_Shared_UVA :401-563
+        paper = os.path.join(root, dataset_size, "processed", "paper")
+        cites = os.path.join(root, dataset_size, "processed", "paper__cites__paper")
+        return {"feat": os.path.join(paper, "node_feat.npy"), "label": os.path.join(paper, f"node_label_{'19' if num_classes == 19 else '2K'}.npy"),
+                "graph_dir": cites}
+    if layout == "OGB":     # OGBDataset_Shared_UVA :687-854
+        raw = os.path.join(root, "raw")
+        return {"feat": os.path.join(raw, "node_feat.npy"), "label": os.path.join(raw, "node_label.npy"), "graph_dir": raw}
+    if layout == "flat":    # everything in one directory (tests, small experiments)
+        return {"feat": os.path.join(root, "node_feat.npy"), "label": os.path.join(root, f"node_label_{num_classes}.npy"), "graph_dir": root}
+    raise ValueError("layout must be 'IGB', 'OGB' or 'flat'")
+
+
 class SharedCSCDataset(object):
     """dataset[0] -> CSCGraph with ndata['label'/'labels'/'train_mask'/'val_mask'/'test_mask'];  .feat_data -> object with
-    data_ptr()/shape over the pinned feature table (what COALA_GNN_DataLoader takes as sim_buf)."""
+    data_ptr()/shape over the pinned feature table (what COALA_GNN_DataLoader takes as sim_buf).
 
-    def __init__(self, root, comm_manager, device, num_classes=19, in_memory=False, shm_name="/coala_shared_feat"):
+    layout = "IGB" (root/<dataset_size>/processed/paper/..., paper__cites__paper/...; masks = the first 60 / next 20 / last 20 % of
+    the node ids, :550-559), "OGB" (root/raw/...; node_label.npy is float with NaN for unlabelled nodes and the 60/20/20 split runs
+    over the labelled ones, :809-843) or "flat" (all files in root, IGB's split rule)."""
+
+    def __init__(self, root, comm_manager, device, num_classes=19, in_memory=False, shm_name="/coala_shared_feat", layout="flat",
+                 dataset_size="experimental"):
         self.root, self.comm, self.device = root, comm_manager, device
-        feat_path = os.path.join(root, "node_feat.npy")
-        feat_mm = np.load(feat_path, mmap_mode=None if in_memory else "r")     # ssd_gnn_dataloader.py:418-423
+        paths = _layout_paths(root, layout, dataset_size, num_classes)
+        feat_mm = np.load(paths["feat"], mmap_mode=None if in_memory else "r")     # ssd_gnn_dataloader.py:418-423
         if feat_mm.dtype != np.float32 or feat_mm.ndim != 2:
             raise ValueError("node_feat.npy must be float32 [num_nodes, dim]")
         self.num_nodes, self.dim = int(feat_mm.shape[0]), int(feat_mm.shape[1])
@@ -77,22 +97,39 @@ class SharedCSCDataset(object):
             for lo in range(0, self.num_nodes, step):
                 host[lo: lo + step] = feat_mm[lo: lo + step]
         comm_manager.local_comm.Barrier()
-        if os.path.exists(os.path.join(root, "csc_indptr.npy")):
-            indptr = torch.from_numpy(np.load(os.path.join(root, "csc_indptr.npy")).astype(np.int64, copy=False))   # :496-515
-            indices = torch.from_numpy(np.load(os.path.join(root, "csc_indices.npy")).astype(np.int64, copy=False))
+        gdir = paths["graph_dir"]
+        if os.path.exists(os.path.join(gdir, "csc_indptr.npy")):
+            indptr = torch.from_numpy(np.load(os.path.join(gdir, "csc_indptr.npy")).astype(np.int64, copy=False))   # :496-515
+            indices = torch.from_numpy(np.load(os.path.join(gdir, "csc_indices.npy")).astype(np.int64, copy=False))
         else:  # no preprocessed CSC: convert the dataset's own edge list on the GPU (the reference's DGL path, :288-319)
-            e_src, e_dst = split_edge_index(np.load(os.path.join(root, "edge_index.npy"), mmap_mode="r"))
-            indptr, indices, _ = csc_from_edge_index(torch.from_numpy(np.ascontiguousarray(e_src)), torch.from_numpy(np.ascontiguousarray(e_dst)),
+            e_src, e_dst = split_edge_index(np.load(os.path.join(gdir, "edge_index.npy"), mmap_mode="r"))
+            indptr, indices, _ = csc_from_edge_index(torch.from_numpy(np.array(e_src)), torch.from_numpy(np.array(e_dst)),
                                                      self.num_nodes, device=device)
-        labels_path = os.path.join(root, f"node_label_{num_classes}.npy")
-        labels = torch.from_numpy(np.load(labels_path).astype(np.int64)) if os.path.exists(labels_path) else torch.zeros(self.num_nodes, dtype=torch.int64)
-        n_train, n_val = int(self.num_nodes * 0.6), int(self.num_nodes * 0.2)        # :550-559
+        labelled = None
+        if os.path.exists(paths["label"]):
+            raw = np.load(paths["label"]).reshape(-1)
+            if np.issubdtype(raw.dtype, np.floating):
+                nan = np.isnan(raw)
+                if nan.any():          # OGB: unlabelled nodes carry NaN; they get label -1 and stay outside every mask
+                    labelled = torch.from_numpy(np.where(~nan)[0])
+                    raw = np.where(nan, -1, raw)
+            labels = torch.from_numpy(raw.astype(np.int64))
+        else:
+            labels = torch.zeros(self.num_nodes, dtype=torch.int64)
         train_mask = torch.zeros(self.num_nodes, dtype=torch.bool)
         val_mask = torch.zeros(self.num_nodes, dtype=torch.bool)
         test_mask = torch.zeros(self.num_nodes, dtype=torch.bool)
-        train_mask[:n_train] = True
-        val_mask[n_train: n_train + n_val] = True
-        test_mask[n_train + n_val:] = True
+        if layout == "OGB":                                                          # :823-843
+            pool = labelled if labelled is not None else torch.arange(self.num_nodes)
+            n_train, n_val = int(0.6 * len(pool)), int(0.2 * len(pool))
+            train_mask[pool[:n_train]] = True
+            val_mask[pool[n_train: n_train + n_val]] = True
+            test_mask[pool[n_train + n_val:]] = True
+        else:                                                                        # :550-559
+            n_train, n_val = int(self.num_nodes * 0.6), int(self.num_nodes * 0.2)
+            train_mask[:n_train] = True
+            val_mask[n_train: n_train + n_val] = True
+            test_mask[n_train + n_val:] = True
         nd = {"label": labels.to(device), "labels": labels.to(device), "train_mask": train_mask, "val_mask": val_mask,
               "test_mask": test_mask}
         self.graph = CSCGraph(indptr.to(device), indices.to(device), ndata=nd)       # :523 (HBM instead of UVA)

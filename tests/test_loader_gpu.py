@@ -336,3 +336,52 @@ def test_shared_csc_dataset_from_edge_index(hiplib, oracle, tmp_path):
     assert torch.equal(d[eids], col) and torch.equal(s[eids], indices)
     same_col = col[1:] == col[:-1]
     assert bool((eids[1:][same_col] > eids[:-1][same_col]).all())   # inside a column: the order of the edge list
+
+
+@pytest.mark.parametrize("layout", ["IGB", "OGB"])
+def test_shared_csc_dataset_reference_directory_layouts(hiplib, oracle, tmp_path, layout):
+    """The two directory trees the reference's loaders read (examples/ssd_gnn_dataloader.py:401-563 IGB, :687-854 OGB): file
+    locations, IGB's first-60/20/20 split by node id, OGB's NaN labels (unlabelled) and its split over the labelled nodes."""
+    import torch
+    from COALA_GNN import MPI_Comm_Manager
+    from COALA_GNN.datasets import SharedCSCDataset
+    rng = np.random.default_rng(2)
+    n, e, dim = 2000, 12000, 16
+    src, dst = rng.integers(0, n, size=e).astype(np.int64), rng.integers(0, n, size=e).astype(np.int64)
+    perm = np.argsort(dst, kind="stable")
+    indptr = np.concatenate([[0], np.cumsum(np.bincount(dst, minlength=n))]).astype(np.int64)
+    feat = oracle.make_features(n, dim, seed=3)
+    if layout == "IGB":
+        paper = tmp_path / "small" / "processed" / "paper"
+        cites = tmp_path / "small" / "processed" / "paper__cites__paper"
+        paper.mkdir(parents=True); cites.mkdir(parents=True)
+        np.save(paper / "node_feat.npy", feat)
+        np.save(paper / "node_label_19.npy", (np.arange(n) % 19).astype(np.float32))
+        np.save(cites / "csc_indptr.npy", indptr); np.save(cites / "csc_indices.npy", src[perm]); np.save(cites / "csc_edge_ids.npy", perm)
+        kw = {"layout": "IGB", "dataset_size": "small"}
+    else:
+        raw = tmp_path / "raw"
+        raw.mkdir()
+        labels = (np.arange(n) % 172).astype(np.float32)
+        labels[rng.random(n) < 0.7] = np.nan                         # papers100M: most nodes carry no label
+        np.save(raw / "node_feat.npy", feat); np.save(raw / "node_label.npy", labels)
+        np.save(raw / "edge_index.npy", np.stack([src, dst], axis=0))  # [2, E]; no preprocessed CSC: converted when opened
+        kw = {"layout": "OGB", "num_classes": 172}
+    comm = MPI_Comm_Manager(0)
+    comm.initialize_nested_process_group("isolated")
+    ds = SharedCSCDataset(str(tmp_path), comm, "cuda:0", shm_name=f"/coala_ds_{layout}_{os.getpid()}", **kw)
+    g = ds[0]
+    assert (g.num_nodes, g.num_edges, ds.dim) == (n, e, dim)
+    assert np.array_equal(g.indptr.cpu().numpy(), indptr) and np.array_equal(g.indices.cpu().numpy(), src[perm])
+    assert np.array_equal(ds.feat_data[::29].cpu().numpy(), feat[::29])
+    tr, va, te = (g.ndata[k].numpy() for k in ("train_mask", "val_mask", "test_mask"))
+    assert not (tr & va).any() and not (tr & te).any() and not (va & te).any()
+    lab = g.ndata["label"].cpu().numpy()
+    if layout == "IGB":
+        assert tr[: int(0.6 * n)].all() and tr.sum() == int(0.6 * n) and va.sum() == int(0.2 * n) and (tr | va | te).all()
+        assert np.array_equal(lab, np.arange(n) % 19)
+    else:
+        known = np.where(~np.isnan(labels))[0]
+        assert np.array_equal(np.where(tr)[0], known[: int(0.6 * len(known))]) and (tr | va | te).sum() == len(known)
+        assert np.array_equal(lab[known], labels[known].astype(np.int64)) and (lab[np.isnan(labels)] == -1).all()
+    ds.close()

@@ -49,7 +49,7 @@ def main():
     src, dst = split_edge_index(e)
     if n_nodes is None:
         n_nodes = int(max(src.max(), dst.max())) + 1
-    indptr, indices, edge_ids = csc_from_edge_index(torch.from_numpy(np.ascontiguousarray(src)), torch.from_numpy(np.ascontiguousarray(dst)),
+    indptr, indices, edge_ids = csc_from_edge_index(torch.from_numpy(np.array(src)), torch.from_numpy(np.array(dst)),
                                                     n_nodes, device=args.device)
     print(f"Indptr shape: {tuple(indptr.shape)} indicies shape:{tuple(indices.shape)} Edge id shape: {tuple(edge_ids.shape)}")  # :280
     print(f"max node: {int(indices.max()) if indices.numel() else -1}")

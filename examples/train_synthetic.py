@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Minimal training script on the MI355X path, shaped like the reference's examples/sbatch_ssd_gnn_train.py:50-195 (same
-objects, same loop, same printed lines) but on seeded synthetic data (no datasets on the box) and without DGL / mpi4py.
+objects, same loop, same printed lines), without DGL / mpi4py: on seeded synthetic data (no datasets on the box), or -- with
+--path -- on a dataset directory in the reference's on-disk layout (--data IGB --dataset_size medium | --data OGB; :202-213, :273-285).
 
   python examples/train_synthetic.py --nodes 200000 --dim 128 --epochs 2
+  python examples/train_synthetic.py --path /data/IGB/ --data IGB --dataset_size medium --cache_size 4096
   python -m torch.distributed.run --nproc-per-node 8 examples/train_synthetic.py --cache_backend nccl ...
 
 The caller of the hot path is out of scope of the port; this file only shows that the loop runs unchanged on the API mirror."""
@@ -40,6 +42,9 @@ def main():
     ap.add_argument("--refresh_counter", type=int, default=10)
     ap.add_argument("--prefetch", type=int, default=0)
     ap.add_argument("--learning_rate", type=float, default=0.01)
+    ap.add_argument("--path", type=str, default=None, help="dataset root in the reference's layout (default: synthetic data)")
+    ap.add_argument("--data", type=str, default="IGB", choices=["IGB", "OGB", "flat"])
+    ap.add_argument("--dataset_size", type=str, default="experimental")
     args = ap.parse_args()
 
     local_rank = int(os.environ.get("LOCAL_RANK", os.environ.get("SLURM_LOCALID", 0)))
@@ -50,22 +55,36 @@ def main():
     comm.initialize_nested_process_group(args.cache_backend)            # :267
     fan_out = [int(f) for f in args.fan_out.split(",")]
 
-    # dataset (synthetic stand-in for IGBDatast_Shared_CSC_UVA, :273): CSC in HBM, features in pinned host memory
-    indptr, indices = powerlaw_csc(args.nodes, 10.0, seed=0, device=device)
-    labels = (torch.arange(args.nodes, device=device) * 7) % args.num_classes
-    feat = alloc_pinned_table(args.nodes, args.dim, seed=0, device=comm.local_rank)
-    n_train = int(0.6 * args.nodes)
-    tmp = tempfile.mkdtemp(prefix="coala_color_")
-    if comm.global_rank == 0:                                           # examples/color_info_gen/generate_color_data.py
-        color, tk, sc, n_col, _ = color_graph(indptr.cpu().numpy(), indices.cpu().numpy(), np.arange(n_train))
-        save_color_files(tmp, color, tk, sc)
-        print(f"num_colors: {n_col}")
-    comm.global_comm.Barrier()
-    if comm.global_size > 1:
-        tmp = comm.global_comm.allgather(tmp)[0]
+    dataset = None
+    if args.path:   # IGBDatast_Shared_CSC_UVA / OGBDataset_Shared_UVA (:273-285): CSC in HBM, features in shared pinned host memory
+        from COALA_GNN.datasets import SharedCSCDataset
+        dataset = SharedCSCDataset(args.path, comm, device, num_classes=args.num_classes, layout=args.data, dataset_size=args.dataset_size)
+        g0 = dataset[0]
+        indptr, indices, labels, feat = g0.indptr, g0.indices, g0.ndata["labels"], dataset.feat_data
+        args.nodes, args.dim = dataset.num_nodes, dataset.dim
+        train_ids = torch.nonzero(g0.ndata["train_mask"], as_tuple=True)[0].clone()                          # :62
+        meta = {"IGB": os.path.join(args.path, args.dataset_size), "OGB": args.path, "flat": args.path}[args.data]   # :55-61
+    else:           # synthetic stand-in
+        indptr, indices = powerlaw_csc(args.nodes, 10.0, seed=0, device=device)
+        labels = (torch.arange(args.nodes, device=device) * 7) % args.num_classes
+        feat = alloc_pinned_table(args.nodes, args.dim, seed=0, device=comm.local_rank)
+        train_ids = torch.arange(int(0.6 * args.nodes))
+        meta = None
+    n_train = len(train_ids)
+    if meta is not None and all(os.path.exists(os.path.join(meta, f)) for f in ("color.npy", "topk.npy", "score.npy")):
+        tmp = meta  # the colouring tool's output next to the dataset, where the reference looks for it
+    else:
+        tmp = tempfile.mkdtemp(prefix="coala_color_")
+        if comm.global_rank == 0:                                       # examples/color_info_gen/generate_color_data.py
+            color, tk, sc, n_col, _ = color_graph(indptr.cpu().numpy(), indices.cpu().numpy(), train_ids.numpy())
+            save_color_files(tmp, color, tk, sc)
+            print(f"num_colors: {n_col}")
+        comm.global_comm.Barrier()
+        if comm.global_size > 1:
+            tmp = comm.global_comm.allgather(tmp)[0]
     files = [os.path.join(tmp, f) for f in ("color.npy", "topk.npy", "score.npy")]
 
-    train_nid = torch.arange(n_train)[torch.randperm(n_train, generator=torch.Generator().manual_seed(0))]   # :62-65
+    train_nid = train_ids[torch.randperm(n_train, generator=torch.Generator().manual_seed(0))]               # :62-65
     nd = Node_Distributor(comm, train_nid, args.batch_size, *files, parsing_method=args.distribution)      # :68
     sampler = NeighborSampler(fan_out)                                                                      # :70-72
     g = sampler.make_graph(indptr, indices, ndata={"labels": labels})
@@ -105,6 +124,8 @@ def main():
     print(f"final loss {loss.item():.4f}")
     comm.global_comm.Barrier()
     del train_loader
+    if dataset is not None:
+        dataset.close()
     comm.destroy_process_group()
 
 

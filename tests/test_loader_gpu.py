@@ -385,3 +385,23 @@ def test_shared_csc_dataset_reference_directory_layouts(hiplib, oracle, tmp_path
         assert np.array_equal(np.where(tr)[0], known[: int(0.6 * len(known))]) and (tr | va | te).sum() == len(known)
         assert np.array_equal(lab[known], labels[known].astype(np.int64)) and (lab[np.isnan(labels)] == -1).all()
     ds.close()
+
+
+def test_example_training_script_on_a_dataset_directory(tmp_path):
+    """examples/train_synthetic.py --path: the reference's IGB directory tree (features, labels, the raw edge list) -> shared pinned
+    cold tier + CSC converted on the GPU -> colouring -> the training loop."""
+    rng = np.random.default_rng(4)
+    n, e, dim = 30000, 240000, 32
+    paper = tmp_path / "small" / "processed" / "paper"
+    cites = tmp_path / "small" / "processed" / "paper__cites__paper"
+    paper.mkdir(parents=True); cites.mkdir(parents=True)
+    np.save(paper / "node_feat.npy", rng.random((n, dim), dtype=np.float32))
+    np.save(paper / "node_label_19.npy", (np.arange(n) % 19).astype(np.float32))
+    np.save(cites / "edge_index.npy", np.stack([rng.integers(0, n, size=e), rng.integers(0, n, size=e)], axis=1).astype(np.int64))
+    root = os.path.dirname(HERE)
+    out = subprocess.run([sys.executable, os.path.join(root, "examples", "train_synthetic.py"), "--path", str(tmp_path), "--data", "IGB",
+                          "--dataset_size", "small", "--batch_size", "128", "--epochs", "1", "--cache_size", "2"],
+                         capture_output=True, text=True, timeout=600, env=dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert out.stdout.count("Epoch Time:") == 1 and "GPU hit ratio:" in out.stdout and "final loss" in out.stdout
+    assert f"Total number of iterations: {int(0.6 * n) // 128 - 1}" in out.stdout

@@ -15,7 +15,7 @@ import torch
 from .Shared_Tensor import Shared_UVA_Tensor_Manager
 from .sampler import CSCGraph
 
-__all__ = ["SharedCSCDataset", "csc_from_edge_index", "split_edge_index"]
+__all__ = ["SharedCSCDataset", "csc_from_edge_index", "split_edge_index", "load_csc_arrays", "load_labels_and_masks", "layout_paths"]
 
 
 def split_edge_index(edge_index):
@@ -57,7 +57,7 @@ def csc_from_edge_index(src, dst, num_nodes, device=None):
     return indptr, indices, edge_ids
 
 
-def _layout_paths(root, layout, dataset_size, num_classes):
+def layout_paths(root, layout, dataset_size, num_classes):
     """Where the reference's loaders look for each file (examples/ssd_gnn_dataloader.py)."""
     if layout == "IGB":     # IGBDatast_Shared_UVA :401-563
         paper = os.path.join(root, dataset_size, "processed", "paper")
@@ -72,6 +72,49 @@ def _layout_paths(root, layout, dataset_size, num_classes):
     raise ValueError("layout must be 'IGB', 'OGB' or 'flat'")
 
 
+def load_csc_arrays(graph_dir, num_nodes, device=None):
+    """csc_indptr.npy / csc_indices.npy of a dataset, or -- when they are missing -- its edge_index.npy converted (on `device`)."""
+    if os.path.exists(os.path.join(graph_dir, "csc_indptr.npy")):
+        indptr = torch.from_numpy(np.load(os.path.join(graph_dir, "csc_indptr.npy")).astype(np.int64, copy=False))   # :496-515
+        indices = torch.from_numpy(np.load(os.path.join(graph_dir, "csc_indices.npy")).astype(np.int64, copy=False))
+        return indptr, indices
+    # no preprocessed CSC: convert the dataset's own edge list (the reference's DGL path, :288-319)
+    e_src, e_dst = split_edge_index(np.load(os.path.join(graph_dir, "edge_index.npy"), mmap_mode="r"))
+    indptr, indices, _ = csc_from_edge_index(torch.from_numpy(np.array(e_src)), torch.from_numpy(np.array(e_dst)), num_nodes, device=device)
+    return indptr, indices
+
+
+def load_labels_and_masks(label_path, num_nodes, layout):
+    """-> (labels int64 [N] with -1 for OGB's unlabelled (NaN) nodes, train / val / test bool masks) by the reference's split rules:
+    the first 60 / next 20 / last 20 % of the node ids (IGB, :550-559), or of the labelled nodes (OGB, :809-843)."""
+    labelled = None
+    if os.path.exists(label_path):
+        raw = np.load(label_path).reshape(-1)
+        if np.issubdtype(raw.dtype, np.floating):
+            nan = np.isnan(raw)
+            if nan.any():
+                labelled = torch.from_numpy(np.where(~nan)[0])
+                raw = np.where(nan, -1, raw)
+        labels = torch.from_numpy(raw.astype(np.int64))
+    else:
+        labels = torch.zeros(num_nodes, dtype=torch.int64)
+    train_mask = torch.zeros(num_nodes, dtype=torch.bool)
+    val_mask = torch.zeros(num_nodes, dtype=torch.bool)
+    test_mask = torch.zeros(num_nodes, dtype=torch.bool)
+    if layout == "OGB":
+        pool = labelled if labelled is not None else torch.arange(num_nodes)
+        n_train, n_val = int(0.6 * len(pool)), int(0.2 * len(pool))
+        train_mask[pool[:n_train]] = True
+        val_mask[pool[n_train: n_train + n_val]] = True
+        test_mask[pool[n_train + n_val:]] = True
+    else:
+        n_train, n_val = int(num_nodes * 0.6), int(num_nodes * 0.2)
+        train_mask[:n_train] = True
+        val_mask[n_train: n_train + n_val] = True
+        test_mask[n_train + n_val:] = True
+    return labels, train_mask, val_mask, test_mask
+
+
 class SharedCSCDataset(object):
     """dataset[0] -> CSCGraph with ndata['label'/'labels'/'train_mask'/'val_mask'/'test_mask'];  .feat_data -> object with
     data_ptr()/shape over the pinned feature table (what COALA_GNN_DataLoader takes as sim_buf).
@@ -83,7 +126,7 @@ class SharedCSCDataset(object):
     def __init__(self, root, comm_manager, device, num_classes=19, in_memory=False, shm_name="/coala_shared_feat", layout="flat",
                  dataset_size="experimental"):
         self.root, self.comm, self.device = root, comm_manager, device
-        paths = _layout_paths(root, layout, dataset_size, num_classes)
+        paths = layout_paths(root, layout, dataset_size, num_classes)
         feat_mm = np.load(paths["feat"], mmap_mode=None if in_memory else "r")     # ssd_gnn_dataloader.py:418-423
         if feat_mm.dtype != np.float32 or feat_mm.ndim != 2:
             raise ValueError("node_feat.npy must be float32 [num_nodes, dim]")
@@ -97,39 +140,8 @@ class SharedCSCDataset(object):
             for lo in range(0, self.num_nodes, step):
                 host[lo: lo + step] = feat_mm[lo: lo + step]
         comm_manager.local_comm.Barrier()
-        gdir = paths["graph_dir"]
-        if os.path.exists(os.path.join(gdir, "csc_indptr.npy")):
-            indptr = torch.from_numpy(np.load(os.path.join(gdir, "csc_indptr.npy")).astype(np.int64, copy=False))   # :496-515
-            indices = torch.from_numpy(np.load(os.path.join(gdir, "csc_indices.npy")).astype(np.int64, copy=False))
-        else:  # no preprocessed CSC: convert the dataset's own edge list on the GPU (the reference's DGL path, :288-319)
-            e_src, e_dst = split_edge_index(np.load(os.path.join(gdir, "edge_index.npy"), mmap_mode="r"))
-            indptr, indices, _ = csc_from_edge_index(torch.from_numpy(np.array(e_src)), torch.from_numpy(np.array(e_dst)),
-                                                     self.num_nodes, device=device)
-        labelled = None
-        if os.path.exists(paths["label"]):
-            raw = np.load(paths["label"]).reshape(-1)
-            if np.issubdtype(raw.dtype, np.floating):
-                nan = np.isnan(raw)
-                if nan.any():          # OGB: unlabelled nodes carry NaN; they get label -1 and stay outside every mask
-                    labelled = torch.from_numpy(np.where(~nan)[0])
-                    raw = np.where(nan, -1, raw)
-            labels = torch.from_numpy(raw.astype(np.int64))
-        else:
-            labels = torch.zeros(self.num_nodes, dtype=torch.int64)
-        train_mask = torch.zeros(self.num_nodes, dtype=torch.bool)
-        val_mask = torch.zeros(self.num_nodes, dtype=torch.bool)
-        test_mask = torch.zeros(self.num_nodes, dtype=torch.bool)
-        if layout == "OGB":                                                          # :823-843
-            pool = labelled if labelled is not None else torch.arange(self.num_nodes)
-            n_train, n_val = int(0.6 * len(pool)), int(0.2 * len(pool))
-            train_mask[pool[:n_train]] = True
-            val_mask[pool[n_train: n_train + n_val]] = True
-            test_mask[pool[n_train + n_val:]] = True
-        else:                                                                        # :550-559
-            n_train, n_val = int(self.num_nodes * 0.6), int(self.num_nodes * 0.2)
-            train_mask[:n_train] = True
-            val_mask[n_train: n_train + n_val] = True
-            test_mask[n_train + n_val:] = True
+        indptr, indices = load_csc_arrays(paths["graph_dir"], self.num_nodes, device=device)
+        labels, train_mask, val_mask, test_mask = load_labels_and_masks(paths["label"], self.num_nodes, layout)
         nd = {"label": labels.to(device), "labels": labels.to(device), "train_mask": train_mask, "val_mask": val_mask,
               "test_mask": test_mask}
         self.graph = CSCGraph(indptr.to(device), indices.to(device), ndata=nd)       # :523 (HBM instead of UVA)

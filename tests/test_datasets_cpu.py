@@ -69,3 +69,29 @@ def test_create_csc_graph_tool_writes_the_reference_files(tmp_path, layout):
     w = _want(edges[:, 0], edges[:, 1], n)
     for name, want in zip(("csc_indptr.npy", "csc_indices.npy", "csc_edge_ids.npy"), w):
         assert np.array_equal(np.load(d / name), want), name
+
+
+def test_generate_color_data_tool(tmp_path):
+    """tools/generate_color_data.py (the reference's examples/color_info_gen/generate_color_data.py): an OGB-style tree holding only
+    the raw edge list and float labels with NaNs -> the three colour files, equal to the library call on the same CSC and the
+    same training nodes (the first 60 % of the LABELLED nodes)."""
+    from COALA_GNN.color_info_gen import color_graph
+    rng = np.random.default_rng(7)
+    n, e = 5000, 40000
+    src, dst = rng.integers(0, n, size=e).astype(np.int64), rng.integers(0, n, size=e).astype(np.int64)
+    labels = (np.arange(n) % 40).astype(np.float32)
+    labels[rng.random(n) < 0.5] = np.nan
+    raw = tmp_path / "raw"
+    raw.mkdir()
+    np.save(raw / "edge_index.npy", np.stack([src, dst], axis=0))
+    np.save(raw / "node_label.npy", labels)
+    out_dir = tmp_path / "colors"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "generate_color_data.py"), "--data", "OGB", "--path", str(tmp_path),
+                          "--num_nodes", str(n), "--out_path", str(out_dir)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "num_colors:" in out.stdout, out.stdout[-1000:] + out.stderr[-2000:]
+    indptr, indices, _ = _want(src, dst, n)
+    known = np.where(~np.isnan(labels))[0]
+    color, tk, sc, n_col, _ = color_graph(indptr, indices, known[: int(0.6 * len(known))])
+    assert np.array_equal(np.load(out_dir / "color.npy"), color)
+    assert np.array_equal(np.load(out_dir / "topk.npy"), tk) and np.array_equal(np.load(out_dir / "score.npy"), sc)
+    assert tk.shape == (n_col, 10) and f"num_colors: {n_col}" in out.stdout

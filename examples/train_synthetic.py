@@ -63,12 +63,14 @@ def main():
         indptr, indices, labels, feat = g0.indptr, g0.indices, g0.ndata["labels"], dataset.feat_data
         args.nodes, args.dim = dataset.num_nodes, dataset.dim
         train_ids = torch.nonzero(g0.ndata["train_mask"], as_tuple=True)[0].clone()                          # :62
+        test_ids = torch.nonzero(g0.ndata["test_mask"], as_tuple=True)[0].clone()                            # :63
         meta = {"IGB": os.path.join(args.path, args.dataset_size), "OGB": args.path, "flat": args.path}[args.data]   # :55-61
     else:           # synthetic stand-in
         indptr, indices = powerlaw_csc(args.nodes, 10.0, seed=0, device=device)
         labels = (torch.arange(args.nodes, device=device) * 7) % args.num_classes
         feat = alloc_pinned_table(args.nodes, args.dim, seed=0, device=comm.local_rank)
         train_ids = torch.arange(int(0.6 * args.nodes))
+        test_ids = torch.arange(int(0.8 * args.nodes), args.nodes)
         meta = None
     n_train = len(train_ids)
     if meta is not None and all(os.path.exists(os.path.join(meta, f)) for f in ("color.npy", "topk.npy", "score.npy")):
@@ -124,6 +126,26 @@ def main():
     print(f"final loss {loss.item():.4f}")
     comm.global_comm.Barrier()
     del train_loader
+
+    # evaluation over the test nodes through a second loader, as the reference does (:156-195)
+    test_nd = Node_Distributor(comm, test_ids, args.batch_size, *files, parsing_method=args.distribution)
+    test_loader = COALA_GNN_DataLoader(SSD_INFO(1, args.dim * 4, 1024, 0), test_nd, g, sampler, args.batch_size, args.dim, fan_out,
+                                       args.cache_size, device, refresh_counter=args.refresh_counter,
+                                       cache_backend=args.cache_backend, sim_buf=feat, shuffle=False, num_rows=args.nodes)
+    model.eval()
+    correct = total = 0
+    with torch.no_grad():
+        for step, (input_nodes, seeds, blocks, fetch_feature) in enumerate(test_loader):
+            if step % 100 == 0:
+                print("Eval step: ", step)
+            blocks = [block.to(device) for block in blocks]
+            batch_labels = blocks[-1].dstdata["labels"].view(-1)
+            pred = model(blocks, fetch_feature).argmax(1)
+            correct += int((pred == batch_labels).sum())
+            total += batch_labels.numel()
+    print("Test Acc {:.2f}%".format(100.0 * correct / max(total, 1)))
+    comm.global_comm.Barrier()
+    del test_loader
     if dataset is not None:
         dataset.close()
     comm.destroy_process_group()

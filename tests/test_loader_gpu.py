@@ -125,7 +125,7 @@ def test_example_training_script_runs():
                          capture_output=True, text=True, timeout=600, env=dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"))
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     assert out.stdout.count("Epoch Time:") == 2 and "GPU hit ratio:" in out.stdout and "Aggregation time:" in out.stdout
-    assert "final loss" in out.stdout
+    assert "final loss" in out.stdout and "Test Acc" in out.stdout      # training, then the evaluation over the test nodes through a second loader
 
 
 def test_loader_modes_are_equivalent(hiplib, oracle, tmp_path):
@@ -403,5 +403,5 @@ def test_example_training_script_on_a_dataset_directory(tmp_path):
                           "--dataset_size", "small", "--batch_size", "128", "--epochs", "1", "--cache_size", "2"],
                          capture_output=True, text=True, timeout=600, env=dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"))
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
-    assert out.stdout.count("Epoch Time:") == 1 and "GPU hit ratio:" in out.stdout and "final loss" in out.stdout
+    assert out.stdout.count("Epoch Time:") == 1 and "GPU hit ratio:" in out.stdout and "final loss" in out.stdout and "Test Acc" in out.stdout
     assert f"Total number of iterations: {int(0.6 * n) // 128 - 1}" in out.stdout

@@ -686,3 +686,60 @@ def test_full_size_eight_inproc_ranks(hiplib, oracle, name, dim, num_rows, cache
         c.close()
     for t in shards:
         t.close()
+
+
+def test_native_fetch_local_failure_does_not_strand_the_peers(hiplib, oracle, monkeypatch):
+    """A rank that fails locally in the middle of the collective sequence (here: bucket counts that do not add up to its batch,
+    detected after the count exchange) aborts the transport: its peers come back with an error instead of waiting for ever, every
+    communicator of the group refuses further fetches, and tearing everything down still works."""
+    import ctypes as C
+    import threading
+    import torch
+    from COALA_GNN.COALA_GNN_Manager import NativeExchange
+    from COALA_GNN_Pybind import _capi
+    monkeypatch.setenv("COALA_INPROC_TIMEOUT_S", "20")
+    L = _capi.load()
+    G, dim, num_rows = 3, 64, 6000
+    feat, tables, caches, orcs = _dist_fixture(hiplib, oracle, G, dim, 1, True, num_rows, seed=3, cls="Isolated_Cache")
+    group = C.c_void_p()
+    _capi.check(L.coala_comm_group_create(G, C.byref(group)))
+    exs = [NativeExchange(None, 0, r, G, 0, inproc_group=group) for r in range(G)]
+    outcome = [None] * G
+    second = [None] * G
+
+    def worker(r):
+        torch.cuda.set_device(0)
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            ids = np.sort(np.random.default_rng(5 + r).choice(num_rows, size=900, replace=False))
+            ids = np.concatenate([ids[ids % G == o] for o in range(G)])          # bucketed by owner
+            cnt = np.array([(ids % G == o).sum() for o in range(G)], dtype=np.int64)
+            if r == 1:
+                cnt[0] += 5                                                      # the counts of rank 1 do not sum to its batch
+            idx, cnt_d = torch.from_numpy(ids).cuda(), torch.from_numpy(cnt).cuda()
+            out = torch.empty((len(ids), dim), dtype=torch.float32, device="cuda")
+            for attempt, slot in ((0, outcome), (1, second)):
+                try:
+                    exs[r].fetch_bucketed(caches[r], out.data_ptr(), idx.data_ptr(), len(ids), cnt_d.data_ptr())
+                    stream.synchronize()
+                    slot[r] = "ok"
+                except RuntimeError as e:
+                    slot[r] = str(e)
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(G)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in threads), "a rank is still waiting for the one that failed"
+    assert "bucket counts sum to" in outcome[1]
+    assert all(o != "ok" for o in outcome), outcome                               # nobody reports success for the broken step
+    assert all("aborted" in s or "destroy it" in s for s in second), second       # and the group stays unusable
+    torch.cuda.synchronize()
+    for e in exs:
+        e.close()
+    _capi.check(L.coala_comm_group_destroy(group))
+    for c in caches:
+        c.close()
+    for t in set(tables):
+        t.close()

@@ -183,6 +183,18 @@ int coala_pinned_free(void* host_ptr) {
 }
 
 // ------------------------------------------------------------------------------------------------ .npy
+// decimal digits -> *v; false when the value does not fit an int64 (a hostile or damaged header: the reference's std::stoll would throw)
+static bool read_dim(const char*& p, const char* end, int64_t* v) {
+    int64_t x = 0;
+    while (p < end && is_digit(*p)) {
+        const int d = *p++ - '0';
+        if (x > (INT64_MAX - d) / 10) return false;
+        x = x * 10 + d;
+    }
+    *v = x;
+    return true;
+}
+
 int coala_npy_parse(const char* buf, size_t len, int want_dim, int64_t* shape, int* ndim_out, size_t* data_off,
                     char* descr, size_t descr_cap) {
     // node_distributor_pybind.cuh:37-109
@@ -216,7 +228,7 @@ int coala_npy_parse(const char* buf, size_t len, int want_dim, int64_t* shape, i
             ++p;
             if (p < end && is_digit(*p)) {
                 int64_t v0 = 0, v1 = 0;
-                while (p < end && is_digit(*p)) v0 = v0 * 10 + (*p++ - '0');
+                if (!read_dim(p, end, &v0)) return fail(COALA_EFORMAT, "a dimension in the .npy header does not fit 63 bits");
                 if (want_dim == 1) { // 'shape':\s?\((\d+),?\)
                     if (p < end && *p == ',') ++p;
                     if (p < end && *p == ')') { shape[0] = v0; *ndim_out = 1; }
@@ -224,7 +236,7 @@ int coala_npy_parse(const char* buf, size_t len, int want_dim, int64_t* shape, i
                     ++p;
                     if (p < end && is_space(*p)) ++p;
                     if (p < end && is_digit(*p)) {
-                        while (p < end && is_digit(*p)) v1 = v1 * 10 + (*p++ - '0');
+                        if (!read_dim(p, end, &v1)) return fail(COALA_EFORMAT, "a dimension in the .npy header does not fit 63 bits");
                         if (p < end && *p == ')') { shape[0] = v0; shape[1] = v1; *ndim_out = 2; }
                     }
                 }

@@ -1,5 +1,6 @@
-"""AddressSanitizer + UBSan over the CPU oracle (the checker everything else is compared against).  GPU sanitizers do not
-exist on the pool: sanitizers run on the CPU build only."""
+"""AddressSanitizer + UBSan over the CPU oracle (the checker everything else is compared against) and over the product's own
+host-side C++ (the .npy parser, the node distributor, the colouring tool).  GPU sanitizers do not exist on the pool: sanitizers
+run on the CPU build only."""
 import os
 import subprocess
 
@@ -15,4 +16,22 @@ def test_oracle_under_asan_ubsan(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "sanitized run ok" in out.stdout
+    assert "ERROR: AddressSanitizer" not in out.stderr and "runtime error" not in out.stderr
+
+
+def test_product_host_code_under_asan_ubsan(tmp_path):
+    """coala_host.cpp + coala_coloring.cpp built with g++ and the sanitizers (HIP headers only for the types: nothing in the driver
+    touches a device), fed good and malformed .npy headers, good and corrupt colour files, a small graph through every colouring
+    entry point.  (Found: a signed overflow in the parser on a 26-digit dimension.)"""
+    exe = str(tmp_path / "san_host")
+    csrc = os.path.join(ROOT, "coala-gnn_amd", "csrc")
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-fno-sanitize-recover=all",
+           "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I", os.path.join(ROOT, "include"),
+           os.path.join(csrc, "coala_host.cpp"), os.path.join(csrc, "coala_coloring.cpp"), os.path.join(ROOT, "tests", "san_host_driver.cpp"),
+           "-o", exe, "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.check_call(cmd)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    out = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "sanitized host run ok" in out.stdout
     assert "ERROR: AddressSanitizer" not in out.stderr and "runtime error" not in out.stderr

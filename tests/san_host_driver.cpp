@@ -83,6 +83,23 @@ int main(int argc, char** argv) {
         (void)coala_npy_parse(bad.data(), bad.size(), 1, shape, &nd, &off, tiny, sizeof tiny);                  // descr buffer too small for "<i8"? (3 chars + NUL fits)
         (void)coala_npy_parse(bad.data(), bad.size(), 1, shape, &nd, &off, tiny, 2);
         CHECK(coala_npy_parse(nullptr, 0, 1, shape, &nd, &off, descr, sizeof descr) != COALA_OK);
+        // seeded mutations of good headers (both versions, both ranks): whatever comes back, no out-of-bounds access and no overflow
+        uint64_t x = 0x9E3779B97F4A7C15ull;
+        for (int it = 0; it < 20000; ++it) {
+            std::string m = npy(it & 1 ? "<i8" : "<f8", it & 2 ? "12," : "3, 4", 1 + ((it >> 2) & 1), v.data(), 96);
+            const int edits = 1 + (it % 4);
+            for (int e = 0; e < edits; ++e) {
+                x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+                const size_t at = (size_t)(x % 140) % m.size();
+                const int kind = (int)((x >> 32) % 4);
+                if (kind == 0) m[at] = (char)(x >> 40);
+                else if (kind == 1) m[at] = "0123456789(),' :"[(x >> 40) % 16];
+                else if (kind == 2) m.erase(at, 1 + (x >> 50) % 5);
+                else m.insert(at, std::string(1 + (x >> 50) % 3, "9(,' "[(x >> 44) % 5]));
+            }
+            const size_t cut = (it % 7 == 0) ? (size_t)(x % (m.size() + 1)) : m.size();
+            (void)coala_npy_parse(m.data(), cut, 1 + (it & 1), shape, &nd, &off, descr, 1 + (size_t)(x % 15));
+        }
     }
     // ---------------------------------------------------------------- node distributor: good files, then a topk entry out of range
     {
@@ -117,6 +134,47 @@ int main(int argc, char** argv) {
         CHECK(coala_distributor_create(items.data(), 0, batch, local, nodes, (tmp + "/missing.npy").c_str(), tf.c_str(), sf.c_str(), &d) != COALA_OK);
         write_file(tf, "\x93NUMPY garbage");                                              // a file that is not a .npy at all
         CHECK(coala_distributor_create(items.data(), 0, batch, local, nodes, cf.c_str(), tf.c_str(), sf.c_str(), &d) != COALA_OK);
+        // files whose headers promise more than they hold, or disagree with each other
+        tk[4] = 1;
+        write_file(tf, npy("<i8", std::to_string(num_colors + 1) + ", " + std::to_string(topk), 1, tk.data(), tk.size() * 8));
+        write_file(cf, npy("<i8", std::to_string(n_items) + ",", 1, color.data(), 100 * 8));                      // 4000 promised, 100 present
+        CHECK(coala_distributor_create(items.data(), 0, batch, local, nodes, cf.c_str(), tf.c_str(), sf.c_str(), &d) != COALA_OK);
+        write_file(cf, npy("<i4", std::to_string(n_items) + ",", 1, color.data(), color.size() * 4));             // wrong element type
+        CHECK(coala_distributor_create(items.data(), 0, batch, local, nodes, cf.c_str(), tf.c_str(), sf.c_str(), &d) != COALA_OK);
+        write_file(cf, npy("<i8", std::to_string(n_items) + ",", 1, color.data(), color.size() * 8));
+        write_file(sf, npy("<f8", std::to_string(num_colors + 1) + ", " + std::to_string(topk - 1), 1, sc.data(), (num_colors + 1) * (topk - 1) * 8));
+        CHECK(coala_distributor_create(items.data(), 0, batch, local, nodes, cf.c_str(), tf.c_str(), sf.c_str(), &d) != COALA_OK);   // topk [10,3] vs score [10,2]
+        write_file(sf, npy("<f8", std::to_string(num_colors + 1) + ", " + std::to_string(topk), 1, sc.data(), sc.size() * 8));
+        for (int64_t bad_color : {(int64_t)-4, (int64_t)num_colors + 2}) {                                        // a colour outside [0, rows of topk]: refused when a step meets it
+            color[17] = bad_color;
+            write_file(cf, npy("<i8", std::to_string(n_items) + ",", 1, color.data(), color.size() * 8));
+            items[3] = 17;
+            d = nullptr;
+            CHECK(coala_distributor_create(items.data(), 0, batch, local, nodes, cf.c_str(), tf.c_str(), sf.c_str(), &d) == COALA_OK && d);
+            if (d) {
+                const int entries = (int)coala_distributor_num_color_entries(d);
+                std::vector<int32_t> m0(entries, 0), m1(entries, 0);
+                const int32_t* meta[2] = {m0.data(), m1.data()};
+                std::vector<int64_t> out(batch * local);
+                CHECK(coala_distributor_assign(d, 0, out.data(), meta, 2) != COALA_OK);
+                CHECK(coala_distributor_destroy(d) == COALA_OK);
+            }
+            items[3] = (3 * 37) % n_items;
+        }
+        color[17] = 3;
+        write_file(cf, npy("<i8", std::to_string(n_items) + ",", 1, color.data(), color.size() * 8));
+        items[5] = n_items + 123;                                                                                // an item id past the colour array
+        d = nullptr;
+        CHECK(coala_distributor_create(items.data(), 0, batch, local, nodes, cf.c_str(), tf.c_str(), sf.c_str(), &d) == COALA_OK && d);
+        if (d) {
+            const int entries = (int)coala_distributor_num_color_entries(d);
+            std::vector<int32_t> m0(entries, 0), m1(entries, 0);
+            const int32_t* meta[2] = {m0.data(), m1.data()};
+            std::vector<int64_t> out(batch * local);
+            CHECK(coala_distributor_assign(d, 0, out.data(), meta, 2) != COALA_OK);
+            CHECK(coala_distributor_destroy(d) == COALA_OK);
+        }
+        items[5] = 5;
         CHECK(coala_distributor_create_plain(items.data(), nodes, &d) == COALA_OK);
         CHECK(coala_distributor_destroy(d) == COALA_OK);
         remove(cf.c_str()); remove(tf.c_str()); remove(sf.c_str());

@@ -17,7 +17,6 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "coala-gnn_amd"))
 
-import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from COALA_GNN import COALA_GNN_DataLoader, MPI_Comm_Manager, Node_Distributor, SSD_INFO  # noqa: E402

@@ -96,7 +96,7 @@ def test_compiled_caches_match_oracle(hiplib, oracle):
     get_cache_data, print_stats) against the oracle; and the Python package's own classes, whose per-step calls go through the
     compiled module, stay bit-identical."""
     import torch
-    from _util import ColorFiles, PinnedTable, synth_colors
+    from _util import ColorFiles, PinnedTable
     nat = hiplib.native
     dim, rows, cache_mb, ncol = 256, 20000, 2, 12
     feat = oracle.make_features(rows, dim, seed=17)

@@ -40,7 +40,7 @@ ctrl = P.SSD_GNN_SSD_Controllers(1, 4096, 1024, 0, 0, dim, True)
 if "--stages" in sys.argv:
     # where the fixed cost goes: K1's dependency chain cut after each link, launched right behind a real step's cold fill
     import ctypes as C
-    from COALA_GNN_Pybind import _capi, current_stream
+    from COALA_GNN_Pybind import current_stream
     L = C.CDLL(os.environ["COALA_HIP_LIB"])
     L.coala_dev_k1_stage.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
     cache = P.Isolated_Cache(ctrl := P.SSD_GNN_SSD_Controllers(1, 4096, 1024, 0, 0, dim, True), None, 0, 1, cache_mb, table.device_ptr, num_rows=rows,

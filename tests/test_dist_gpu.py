@@ -2,6 +2,8 @@
 serve / scatter kernels and the AllToAllExchange host logic's contract against the oracle's collective step
 (orc_dist_fetch: COALA_GNN_Manager.py:143-211, ssd_gnn_cache.cuh:111-174).  The RCCL transport itself is covered by
 test_manager_world1_gpu (1-rank RCCL group) and by the gloo world-2 CPU tests."""
+import os
+
 import numpy as np
 import pytest
 
@@ -196,7 +198,7 @@ def test_native_fetch_inproc_ranks_match_oracle(hiplib, oracle, G, dim, cache_mb
     group = C.c_void_p()
     _capi.check(L.coala_comm_group_create(G, C.byref(group)))
     exs = [NativeExchange(None, 0, r, G, 0, inproc_group=group, rounds=rounds) for r in range(G)]
-    rng = np.random.default_rng(77 + G)
+    rng = np.random.default_rng(77 + G + 1000 * int(os.environ.get("COALA_TEST_SEED", "0")))   # COALA_TEST_SEED: soak runs over other plans
     plan = []
     for step in range(steps):
         sizes = [int(rng.integers(0, 3000)) if step else 1500 for _ in range(G)]

@@ -12,6 +12,7 @@ COALA_K1_GRID=8192 bash tools/k1_stages_profile.sh > /dev/null 2>&1; grep -v "am
 bash tools/k1_variants.sh > /dev/null 2>&1; cp $R/gpurun_out/r02_k1_variants.txt $O/${ROUND}_k1_variants.txt; echo "k1 variants rc=$?"
 python3 tools/k1_dim_sweep.py 2>&1 | grep -v amdgpu.ids > $O/${ROUND}_k1_hit_sweep.txt; echo "dim sweep rc=$?"
 (for g in 1024 4096 16384 65536; do COALA_K1_GRID=$g python3 tools/k1_big_batch_grid.py 2>&1 | grep "^GRID"; done) > $O/${ROUND}_k1_big_batches.body; echo "k1 big batches rc=$?"
+bash tools/dist_overlap_profile.sh > /dev/null 2>&1; cp $R/gpurun_out/r02_dist_overlap.txt $O/${ROUND}_dist_overlap.body; echo "dist overlap rc=$?"
 python3 tools/fetch_gap_probe.py 2>&1 | grep -v amdgpu.ids > $O/${ROUND}_prefetch_fetch_gaps.txt; echo "gap probe rc=$?"
 (echo "# tools/sampler_fanout_probe.py (MI355X; 10 M-node power-law graph, 1024 seeds; round 1: 0.107 / 0.110 / 0.210 / 0.197 ms for 5,5 / 10,10 / 15,10,5 / 10,10,10)"; python3 tools/sampler_fanout_probe.py 2>&1 | grep -v amdgpu.ids) > $O/${ROUND}_sampler_fanouts.txt; echo "sampler rc=$?"
 python3 tools/backend_compare_probe.py 2>/dev/null | grep "^{" | python3 -m json.tool > $O/${ROUND}_backend_compare.json; echo "backend compare rc=$?"

@@ -379,8 +379,10 @@ def _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, dev
     torch.cuda.synchronize()
     # parity self-check on every rank, untimed: the rows this path just delivered == the synthetic table's formula, bit for bit.
     # (At N>1 this is the first time the exchange runs over real RCCL links: a wrong row must stop the run, not be timed.)
-    chk_ids = batches[0][0]
-    got = manager.fetch_feature(batches[0])[-1]
+    # (with --warmup 0 batches[0] is the first TIMED minibatch: checking it here would cache its rows ahead of the clock)
+    chk_batch = batches[0] if args.warmup > 0 else ids_for(total_steps + 100)
+    chk_ids = chk_batch[0]
+    got = manager.fetch_feature(chk_batch)[-1]
     want = feature_rows_torch(chk_ids, args.dim, args.seed)
     if not torch.equal(got, want):
         bad = int((got != want).any(dim=1).sum())

@@ -26,6 +26,13 @@ for _p in (ROOT, PKG):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
+# HIP maps the streams of a process onto GPU_MAX_HW_QUEUES hardware queues (default 4) in creation order; two streams that land on
+# one queue run their kernels one after the other.  At N > 1 a rank has the caller's stream, the exchange's stream, RCCL's and the
+# loader's fetch and sampler streams: with 4 queues the cold fill and the row exchange can end up on the same one and lose their
+# overlap (seen on one GPU: two logical ranks' fills serialised on queue 4, tools/dist_overlap_trace.py).  Must be set before the
+# HIP runtime starts; a value already in the environment wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -542,7 +549,7 @@ def _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, dev
                        "exchange_transport": (exchange_note or getattr(manager, "exchange_kind", None)) if world > 1 else None,
                        "rccl_ranks": (getattr(manager.exchange, "rccl_ranks", None) or
                                       (dist.get_world_size(comm.nccl_cache_gather) if not single_dev else None)) if world > 1 else None,
-                       "exchange_rounds": rounds_probe,
+                       "exchange_rounds": rounds_probe, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "input_nodes": "bucketed by owner by the sampler (no routing pass, rows received in place)" if bucket else "sampler order",
                        "parity_check": "rows of one warm-up minibatch == synthetic table formula, bit-exact, on every rank", "cold_tier": "HBM" if args.cold_tier == "hbm" else ("pinned host, owner-partitioned" if cold_partitioned else "pinned host"),
                        "prewarm_steps": args.prewarm, "rows_scale_factor": rows_scale,

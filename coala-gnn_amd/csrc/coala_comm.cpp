@@ -229,7 +229,16 @@ int finish_create(coala_comm* c) {
         const int r = atoi(e);
         if (r >= 1 && r <= kMaxRounds) c->rounds = r;
     }
-    if (hipStreamCreateWithFlags(&c->cs, hipStreamNonBlocking) != hipSuccess) return fail(COALA_EHIP, "hipStreamCreate failed");
+    // The communication stream gets the highest stream priority: HIP keeps priority levels on separate hardware queues, so the row
+    // exchange can never be queued behind the cold fill it is meant to run beside (with equal priorities the streams of a process
+    // share GPU_MAX_HW_QUEUES = 4 queues in creation order), and its few workgroups are scheduled ahead of the fill's.
+    int prio_least = 0, prio_greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess ||
+        hipStreamCreateWithPriority(&c->cs, hipStreamNonBlocking, prio_greatest) != hipSuccess) {
+        (void)hipGetLastError();
+        c->cs = nullptr;
+        if (hipStreamCreateWithFlags(&c->cs, hipStreamNonBlocking) != hipSuccess) return fail(COALA_EHIP, "hipStreamCreate failed");
+    }
     for (int k = 0; k < kMaxRounds; ++k)
         if (hipEventCreateWithFlags(&c->ev_fill[k], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&c->ev_x[k], hipEventDisableTiming) != hipSuccess)

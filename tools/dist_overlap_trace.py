@@ -94,21 +94,26 @@ def summarize(path, last_steps):
     fills = [e for e in ev if e[2] == "fill" and e[1] - e[0] > 20000]                      # cold fills that move rows (> 20 us)
     copies = [e for e in ev if e[2] == "copy" and e[1] - e[0] > 3000]                      # row copies (the id copies are shorter)
     fills = fills[-last_steps:]
-    inside = total_cp = 0
-    ov_ns = 0
     print(f"# {len(fills)} cold-fill launches (last of the run), {len(copies)} row copies in the whole trace; times in us relative to each fill's start")
     for f0, f1, _, q in fills:
         started = [(c0 - f0, c1 - f0) for c0, c1, _, cq in copies if f0 <= c0 < f1]
-        ov = sum(min(c1, f1) - max(c0, f0) for c0, c1, _, cq in copies if c0 < f1 and c1 > f0)
-        ov_ns += ov
-        inside += len(started)
         show = ", ".join(f"[{a / 1e3:.0f}..{b / 1e3:.0f}]" for a, b in started[:6])
         print(f"fill on queue {q}: {(f1 - f0) / 1e3:7.1f} us; row copies that STARTED while it ran: {len(started):2d}  {show}")
     first, last = fills[0][0], fills[-1][1]
-    total_cp = sum(1 for c0, c1, _, _ in copies if first <= c0 <= last)
-    cp_ns = sum(c1 - c0 for c0, c1, _, _ in copies if first <= c0 <= last)
-    print(f"# in that window: {total_cp} row copies, {inside} of them started inside a cold fill of some rank; "
-          f"{ov_ns / 1e3:.0f} us of copy time overlapped fill time, of {cp_ns / 1e3:.0f} us of copy time in all")
+    # every row copy of the window against the UNION of the fill intervals (two ranks' fills can run at once)
+    iv = sorted((f0, f1) for f0, f1, _, _ in fills)
+    merged = []
+    for a0, a1 in iv:
+        if merged and a0 <= merged[-1][1]:
+            merged[-1][1] = max(merged[-1][1], a1)
+        else:
+            merged.append([a0, a1])
+    win = [(c0, c1) for c0, c1, _, _ in copies if first <= c0 <= last]
+    cp_ns = sum(c1 - c0 for c0, c1 in win)
+    ov_ns = sum(max(0, min(c1, m1) - max(c0, m0)) for c0, c1 in win for m0, m1 in merged)
+    began_inside = sum(1 for c0, c1 in win if any(m0 <= c0 < m1 for m0, m1 in merged))
+    print(f"# in that window: {len(win)} row copies, {began_inside} of them began while a cold fill was running; "
+          f"{ov_ns / 1e3:.0f} us of their {cp_ns / 1e3:.0f} us ran beside a fill ({100.0 * ov_ns / max(cp_ns, 1):.0f} %)")
 
 
 if __name__ == "__main__":

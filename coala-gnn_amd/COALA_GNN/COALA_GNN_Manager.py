@@ -84,7 +84,8 @@ class AllToAllExchange(object):
         self._both_host = torch.zeros((2, world), dtype=torch.int64, pin_memory=on_gpu)
         # persistent workspaces, grown on demand (no per-step allocation)
         self._ws = {}
-        self._side = torch.cuda.Stream(device=device) if (on_gpu and world > 1 and not self.stage_through_host) else None
+        # (high priority = a hardware queue of its own, as the native call's communication stream)
+        self._side = torch.cuda.Stream(device=device, priority=-1) if (on_gpu and world > 1 and not self.stage_through_host) else None
         self.last_send_counts = None
         self.last_recv_counts = None
         # profile = True brackets the row exchange with HIP events (bench.py's xGMI figure: BASELINE.md "achieved_xGMI")

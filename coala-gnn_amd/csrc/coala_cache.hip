@@ -160,7 +160,7 @@ constexpr int kK1MaxWaves = kK1Waves;
 template <typename V> __device__ __forceinline__ V nt_load(const V* p) { return __builtin_nontemporal_load(p); }
 template <typename V> __device__ __forceinline__ void nt_store(V v, V* p) { __builtin_nontemporal_store(v, p); }
 // K1's row moves: nontemporal loads of the lines (touched once per batch: keeps them from displacing the tag sets; plain loads are
-// 0.5 us faster at 32 % hits but 3 us slower on an all-hit batch), plain stores of the output rows (0.3-0.4 us faster than
+// 3 us slower on an all-hit batch and no faster at 32 % hits -- 17.4 us either way in situ, as is a per-chunk choice between the two), plain stores of the output rows (0.3-0.4 us faster than
 // nontemporal ones in situ and on the all-hit batch, and the consumer reads them next).  Development builds can flip either
 // with -DK1_PLAIN_LOADS / -DK1_NT_STORES (tools/k1_insitu.py).
 template <typename V> __device__ __forceinline__ V k1_load(const V* p) {

@@ -52,6 +52,9 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--cache-mb", type=int, default=4096)
     ap.add_argument("--avg-degree", type=float, default=12.0)
+    ap.add_argument("--counts-ahead", action="store_true",
+                    help="N>1, native exchange: the count exchange of minibatch s+1 is issued (side stream) before the fetch of minibatch s, "
+                         "which then runs without its host synchronisation (coala_comm_counts_begin); off by default")
     ap.add_argument("--rounds", type=int, default=0, help="N>1: row-exchange rounds per fetch (1..8); default: measured during the warm-up")
     ap.add_argument("--no-tune-rounds", action="store_true", help="N>1: keep the default number of exchange rounds (2) instead of measuring")
     ap.add_argument("--prewarm", type=int, default=400, help="untimed minibatches that bring the cache to steady state")
@@ -403,6 +406,15 @@ def _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, dev
         xch.reset_profile()
         xch.profile = True
 
+    ahead = bool(args.counts_ahead and world > 1 and bucket and hasattr(manager.exchange, "counts_begin") and args.mode == "minibatch")
+    if ahead:   # the loaders' pipeline (counts_ahead=True) on pre-sampled minibatches: exchange s+1's counts, then fetch s
+        side = torch.cuda.Stream(device=device)
+
+        def counts_for(s):
+            blk = batches[s][2][0]
+            with torch.cuda.stream(side):
+                blk.counts_ticket = manager.exchange.counts_begin(blk.owner_counts.data_ptr())
+
     # ---------------------------------------------------------------- timed region
     # The interpreter's full (generation-2) garbage collection walks every object torch and numpy have created -- 25-60 ms in this
     # process -- and fires at an allocation count that depends on --steps (it landed inside the timed region for --steps 50 and
@@ -417,7 +429,11 @@ def _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, dev
     torch.cuda.synchronize()
     t_start = time.perf_counter()
     rows_done = 0
+    if ahead:
+        counts_for(args.warmup)
     for s in range(args.warmup, args.warmup + args.steps):
+        if ahead and s + 1 < args.warmup + args.steps:
+            counts_for(s + 1)
         out = manager.fetch_feature(batches[s])[-1]
         rows_done += out.shape[0]
     torch.cuda.synchronize()
@@ -549,7 +565,7 @@ def _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, dev
                        "exchange_transport": (exchange_note or getattr(manager, "exchange_kind", None)) if world > 1 else None,
                        "rccl_ranks": (getattr(manager.exchange, "rccl_ranks", None) or
                                       (dist.get_world_size(comm.nccl_cache_gather) if not single_dev else None)) if world > 1 else None,
-                       "exchange_rounds": rounds_probe, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
+                       "exchange_rounds": rounds_probe, "counts_ahead": bool(ahead), "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "input_nodes": "bucketed by owner by the sampler (no routing pass, rows received in place)" if bucket else "sampler order",
                        "parity_check": "rows of one warm-up minibatch == synthetic table formula, bit-exact, on every rank", "cold_tier": "HBM" if args.cold_tier == "hbm" else ("pinned host, owner-partitioned" if cold_partitioned else "pinned host"),
                        "prewarm_steps": args.prewarm, "rows_scale_factor": rows_scale,

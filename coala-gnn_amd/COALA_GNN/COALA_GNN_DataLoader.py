@@ -135,13 +135,17 @@ class SSD_INFO(object):  # COALA_GNN_DataLoader.py:80-90
 class COALA_GNN_DataLoader(torch.utils.data.DataLoader):
     def __init__(self, SSD_info, node_distributor, graph, graph_sampler, batch_size, dim, fan_out, cache_size, device,
                  refresh_counter=10, cache_backend="nvshmem", sim_buf=None, shuffle=False, num_rows=None, profile=False,
-                 prefetch=0, cold_partitioned=False, sync_fetch=False):
+                 prefetch=0, cold_partitioned=False, sync_fetch=False, counts_ahead=False):
         # like the reference, torch's DataLoader.__init__ is never called: this is a plain iterator
         # prefetch = 0: the reference's strictly serial __next__ (:149-167).  prefetch = k > 0: a producer thread runs
         # distribute -> sample -> fetch for the next k steps on its own HIP stream while the consumer trains (SURVEY f-2).
         # sync_fetch = True: the reference's fetch_feature, which returns only when the rows are in place.  False (default):
         # the fetch is only ENQUEUED on the current stream -- the training step that follows is ordered behind it by the stream,
         # and its launch overhead (about 1 ms of host time for the GraphSAGE step) overlaps the fetch instead of following it.
+        # counts_ahead = True (opt-in; native exchange + a sampler that buckets by owner): the count exchange of a distributed fetch is
+        # issued right behind the sample, two steps before its fetch, so the fetch itself needs no host synchronisation
+        # (coala_comm_counts_begin).  Every rank of the cache group must use the same setting.
+        self.counts_ahead = bool(counts_ahead)
         self.prefetch = int(prefetch)
         self._producer = None
         self._queue = None
@@ -196,17 +200,23 @@ class COALA_GNN_DataLoader(torch.utils.data.DataLoader):
         with torch.cuda.stream(self._side_stream):
             seeds = self.scheduler.run(is_last_iter)
         self._sampled += 1
+        ticket = None
         with torch.cuda.stream(self._sample_stream):
             pending = self.sampler.sample_begin(self.g, seeds.to(self.device))
+            xch = self.COALA_GNN_Manager.exchange
+            if self.counts_ahead and pending[6] is not None and hasattr(xch, "counts_begin"):
+                ticket = xch.counts_begin(pending[6][1].data_ptr())   # the owner counts the sampler just produced (device)
             ev = torch.cuda.Event()
             ev.record()
-        return pending, ev
+        return pending, ev, ticket
 
     def _enqueue_fetch(self):
         """The sample launched earlier -> its fetch ENQUEUED on the fetch stream; -> (item, event that marks its rows complete)."""
-        pending, ev_s = self._ahead
+        pending, ev_s, ticket = self._ahead
         self._ahead = None
         batch = self.sampler.sample_end(pending)  # counts of a sample enqueued a whole step ago: no wait in steady state
+        if ticket is not None:
+            batch[2][0].counts_ticket = ticket
         fs = self._side_stream
         with torch.cuda.stream(fs):
             fs.wait_event(ev_s)

@@ -336,10 +336,21 @@ class NativeExchange(object):
         self._lib.coala_comm_last_counts(self._h, send, recv)
         self.last_send_counts, self.last_recv_counts = list(send), list(recv)
 
-    def fetch_bucketed(self, ops, out_ptr, idx_ptr, n, counts_ptr):
-        """idx already bucketed by owner (NeighborSampler(bucket_by_owner=G)): no routing pass, rows received in place."""
+    def counts_begin(self, counts_ptr):
+        """Issue the count exchange of a later fetch_bucketed now, on the current stream (collective; no host wait) -> ticket."""
+        from COALA_GNN_Pybind import current_stream
+        t = self._C.c_int64(-1)
+        self._capi.check(self._lib.coala_comm_counts_begin(self._h, int(counts_ptr), current_stream(), self._C.byref(t)))
+        return int(t.value)
+
+    def fetch_bucketed(self, ops, out_ptr, idx_ptr, n, counts_ptr, ticket=None):
+        """idx already bucketed by owner (NeighborSampler(bucket_by_owner=G)): no routing pass, rows received in place.
+        ticket = a counts_begin of the same counts issued earlier: the fetch then runs without a host synchronisation."""
         from COALA_GNN_Pybind import current_stream, native
-        if native is not None:
+        if ticket is not None:
+            self._capi.check(self._lib.coala_cache_fetch_distributed_bucketed_ahead(ops._h, self._h, int(out_ptr) or None, int(idx_ptr) or None,
+                                                                                     int(n), int(ticket), current_stream()))
+        elif native is not None:
             native.cache_fetch_distributed_bucketed(ops._h.value or 0, self._h.value or 0, int(out_ptr), int(idx_ptr), int(n), int(counts_ptr),
                                                     current_stream())
         else:
@@ -466,7 +477,11 @@ class COALA_GNN_Manager(object):
                 owner_counts = oc
         if owner_counts is not None:
             return_torch = torch.empty([index_size, self.dim], dtype=torch.float, device=self.device)
-            self.exchange.fetch_bucketed(self.COALA_GNN_Cache, return_torch.data_ptr(), index_ptr, index_size, owner_counts.data_ptr())
+            ticket = getattr(batch[2][0], "counts_ticket", None)   # the count exchange was issued ahead (loader, counts_ahead=True)
+            if ticket is not None:
+                self.exchange.fetch_bucketed(self.COALA_GNN_Cache, return_torch.data_ptr(), index_ptr, index_size, owner_counts.data_ptr(), ticket=ticket)
+            else:
+                self.exchange.fetch_bucketed(self.COALA_GNN_Cache, return_torch.data_ptr(), index_ptr, index_size, owner_counts.data_ptr())
         elif self.cache_backend == "nvshmem":
             return_torch = self.NVshmem_tensor_manager.get_batch_tensor([index_size, self.dim])
             request_tensor_ptr = self.NVshmem_tensor_manager.get_index_tensor_ptr()

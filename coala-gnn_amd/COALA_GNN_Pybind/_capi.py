@@ -79,6 +79,8 @@ SYMBOLS = {
     "coala_comm_last_counts": (_I, [_VP, _VP, _VP]),
     "coala_cache_fetch_distributed": (_I, [_VP, _VP, _VP, _VP, _I64, _VP]),
     "coala_cache_fetch_distributed_bucketed": (_I, [_VP, _VP, _VP, _VP, _I64, _VP, _VP]),
+    "coala_comm_counts_begin": (_I, [_VP, _VP, _VP, _VP]),
+    "coala_cache_fetch_distributed_bucketed_ahead": (_I, [_VP, _VP, _VP, _VP, _I64, _I64, _VP]),
     "coala_cache_color_counts": (_I, [_VP, _VP, C.c_int32, _VP]),
     "coala_cache_color_counts_async": (_I, [_VP, C.c_int32, _VP]),
     "coala_cache_color_counts_finish": (_I, [_VP, _VP, C.c_int32]),

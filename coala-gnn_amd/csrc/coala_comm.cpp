@@ -218,6 +218,12 @@ struct coala_comm {
     std::vector<hipEvent_t> prof_pool;
     coala_comm_profile_t prof{};
     bool broken = false;
+    // count exchanges issued ahead of their fetch (coala_comm_counts_begin): ring of device [2G] + pinned [2G] + event
+    static constexpr int kCountsRing = 8;
+    int64_t* ahead_dev = nullptr;   // [kCountsRing][2G]
+    int64_t* ahead_host = nullptr;  // pinned [kCountsRing][2G]
+    hipEvent_t ahead_ev[kCountsRing] = {};
+    uint64_t ahead_calls = 0;
 };
 
 namespace {
@@ -248,6 +254,12 @@ int finish_create(coala_comm* c) {
         return fail(COALA_ENOMEM, "communicator workspace allocation failed");
     c->last_send.assign(c->nranks, 0);
     c->last_recv.assign(c->nranks, 0);
+    const size_t ring_words = (size_t)coala_comm::kCountsRing * 2 * (size_t)c->nranks;
+    if (hipMalloc((void**)&c->ahead_dev, ring_words * sizeof(int64_t)) != hipSuccess ||
+        hipHostMalloc((void**)&c->ahead_host, ring_words * sizeof(int64_t)) != hipSuccess)
+        return fail(COALA_ENOMEM, "communicator workspace allocation failed");
+    for (int k = 0; k < coala_comm::kCountsRing; ++k)
+        if (hipEventCreateWithFlags(&c->ahead_ev[k], hipEventDisableTiming) != hipSuccess) return fail(COALA_EHIP, "hipEventCreate failed");
     return COALA_OK;
 }
 
@@ -390,7 +402,10 @@ int coala_comm_destroy(coala_comm_t* c) {
         if (c->ev_x[k]) (void)hipEventDestroy(c->ev_x[k]);
     }
     if (c->cs) (void)hipStreamDestroy(c->cs);
-    void* dev[] = {c->node, c->map, c->recv_ids, c->rows_send, c->rows_recv, c->counts_dev};
+    for (int k = 0; k < coala_comm::kCountsRing; ++k)
+        if (c->ahead_ev[k]) (void)hipEventDestroy(c->ahead_ev[k]);
+    if (c->ahead_host) (void)hipHostFree(c->ahead_host);
+    void* dev[] = {c->node, c->map, c->recv_ids, c->rows_send, c->rows_recv, c->counts_dev, c->ahead_dev};
     for (void* p : dev)
         if (p) (void)hipFree(p);
     if (c->counts_host) (void)hipHostFree(c->counts_host);
@@ -427,21 +442,58 @@ int coala_comm_profile(coala_comm_t* c, int enable, coala_comm_profile_t* out, i
     return COALA_OK;
 }
 
-static int fetch_impl(coala_cache_t* h, coala_comm_t* c, float* out, const int64_t* idx, int64_t n, const int64_t* bucket_counts_dev, void* stream);
+static int fetch_impl(coala_cache_t* h, coala_comm_t* c, float* out, const int64_t* idx, int64_t n, const int64_t* bucket_counts_dev,
+                      const int64_t* counts_host, void* stream);
 
 int coala_cache_fetch_distributed(coala_cache_t* h, coala_comm_t* c, float* out, const int64_t* idx, int64_t n, void* stream) {
-    return fetch_impl(h, c, out, idx, n, nullptr, stream);
+    return fetch_impl(h, c, out, idx, n, nullptr, nullptr, stream);
 }
 
 int coala_cache_fetch_distributed_bucketed(coala_cache_t* h, coala_comm_t* c, float* out, const int64_t* idx, int64_t n,
                                            const int64_t* counts_dev, void* stream) {
     if (!counts_dev) return fail(COALA_EINVAL, "null bucket counts");
-    return fetch_impl(h, c, out, idx, n, counts_dev, stream);
+    return fetch_impl(h, c, out, idx, n, counts_dev, nullptr, stream);
+}
+
+int coala_comm_counts_begin(coala_comm_t* c, const int64_t* counts_dev, void* stream, int64_t* ticket_out) {
+    if (!c || !counts_dev || !ticket_out) return fail(COALA_EINVAL, "null argument");
+    if (c->broken) return fail(COALA_ECOMM, "this communicator failed in an earlier fetch and was aborted: destroy it");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int G = c->nranks;
+    const int slot = (int)(c->ahead_calls % coala_comm::kCountsRing);
+    if (c->ahead_calls >= coala_comm::kCountsRing) HIPCHK(hipEventSynchronize(c->ahead_ev[slot])); // the slot's previous exchange has landed
+    int64_t* dev = c->ahead_dev + (size_t)slot * 2 * G;
+    int64_t* host = c->ahead_host + (size_t)slot * 2 * G;
+    HIPCHK(hipMemcpyAsync(dev, counts_dev, (size_t)G * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
+    if (int rc = c->tr->all_to_all_i64(dev, dev + G, st)) { // a collective: a failure here strands the peers -> abort
+        c->broken = true;
+        c->tr->abort();
+        return rc;
+    }
+    HIPCHK(hipMemcpyAsync(host, dev, 2 * (size_t)G * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(c->ahead_ev[slot], st));
+    *ticket_out = (int64_t)c->ahead_calls++;
+    return COALA_OK;
+}
+
+int coala_cache_fetch_distributed_bucketed_ahead(coala_cache_t* h, coala_comm_t* c, float* out, const int64_t* idx, int64_t n, int64_t ticket,
+                                                 void* stream) {
+    if (!c) return fail(COALA_EINVAL, "null handle");
+    if (ticket < 0 || (uint64_t)ticket >= c->ahead_calls || c->ahead_calls - (uint64_t)ticket > (uint64_t)coala_comm::kCountsRing)
+        return fail(COALA_EINVAL, "ticket %lld is not one of the last %d count exchanges", (long long)ticket, coala_comm::kCountsRing);
+    HIPCHK(hipSetDevice(c->device));
+    const int slot = (int)((uint64_t)ticket % coala_comm::kCountsRing);
+    HIPCHK(hipEventSynchronize(c->ahead_ev[slot])); // issued a step or two ago: normally complete long since
+    return fetch_impl(h, c, out, idx, n, c->ahead_dev + (size_t)slot * 2 * c->nranks, c->ahead_host + (size_t)slot * 2 * c->nranks, stream);
 }
 
 // bucket_counts_dev == nullptr: route here.  Otherwise idx is already bucketed by owner: node = idx, the map is the identity,
 // the rows of every peer are received straight into `out` and nothing is un-permuted.
-static int fetch_impl(coala_cache_t* h, coala_comm_t* c, float* out, const int64_t* idx, int64_t n, const int64_t* bucket_counts_dev, void* stream) {
+// counts_host != nullptr: the 2G counts were exchanged ahead (coala_comm_counts_begin) and are on the host already -- no count
+// exchange, no host synchronisation in this call.
+static int fetch_impl(coala_cache_t* h, coala_comm_t* c, float* out, const int64_t* idx, int64_t n, const int64_t* bucket_counts_dev,
+                      const int64_t* counts_host, void* stream) {
     if (!h || !c) return fail(COALA_EINVAL, "null handle");
     const bool bucketed = bucket_counts_dev != nullptr;
     if (c->broken) return fail(COALA_ECOMM, "this communicator failed in an earlier fetch and was aborted: destroy it");
@@ -471,7 +523,7 @@ static int fetch_impl(coala_cache_t* h, coala_comm_t* c, float* out, const int64
     const int64_t* node = c->node;
     float* rows_recv = c->rows_recv;
     if (bucketed) {
-        HIPCHK(hipMemcpyAsync(send_cnt, bucket_counts_dev, (size_t)G * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
+        if (!counts_host) HIPCHK(hipMemcpyAsync(send_cnt, bucket_counts_dev, (size_t)G * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
         node = idx;
         rows_recv = out; // bucket order IS the caller's order
     } else if ((rc = coala_cache_route(h, idx, n, G, 0, c->node, c->map, send_cnt, offsets, st))) {
@@ -484,17 +536,20 @@ static int fetch_impl(coala_cache_t* h, coala_comm_t* c, float* out, const int64
         c->tr->abort();
         return code;
     };
-    // 2. counts: every rank tells every owner how many ids follow
-    if ((rc = c->tr->all_to_all_i64(send_cnt, recv_cnt, st))) return broke(rc);
-    // 3. the one host read of the step
-    if (hipMemcpyAsync(c->counts_host, c->counts_dev, 2 * (size_t)G * sizeof(int64_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipStreamSynchronize(st) != hipSuccess)
-        return broke(fail(COALA_EHIP, "reading the exchange counts failed: %s", hipGetErrorString(hipGetLastError())));
+    if (!counts_host) {
+        // 2. counts: every rank tells every owner how many ids follow
+        if ((rc = c->tr->all_to_all_i64(send_cnt, recv_cnt, st))) return broke(rc);
+        // 3. the one host read of the step
+        if (hipMemcpyAsync(c->counts_host, c->counts_dev, 2 * (size_t)G * sizeof(int64_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess)
+            return broke(fail(COALA_EHIP, "reading the exchange counts failed: %s", hipGetErrorString(hipGetLastError())));
+        counts_host = c->counts_host;
+    }
     std::vector<size_t> scnt(G), sdis(G), rcnt(G), rdis(G);
     size_t total_recv = 0, acc = 0;
     for (int p = 0; p < G; ++p) {
-        scnt[p] = (size_t)c->counts_host[p];
-        rcnt[p] = (size_t)c->counts_host[G + p];
+        scnt[p] = (size_t)counts_host[p];
+        rcnt[p] = (size_t)counts_host[G + p];
         sdis[p] = acc;
         rdis[p] = total_recv;
         acc += scnt[p];

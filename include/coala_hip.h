@@ -196,6 +196,15 @@ int coala_cache_fetch_distributed(coala_cache_t* h, coala_comm_t* c, float* out,
  * out[i] = row of idx[i] as above. */
 int coala_cache_fetch_distributed_bucketed(coala_cache_t* h, coala_comm_t* c, float* out, const int64_t* idx, int64_t n,
                                            const int64_t* counts_dev, void* stream);
+/* The bucketed fetch without its host synchronisation (opt-in): the count exchange is split off and issued AHEAD -- typically right
+ * behind the sampler that produced counts_dev, on the sampler's stream, one or two steps before the fetch -- and the fetch then
+ * finds both count vectors on the host.  coala_comm_counts_begin is a collective (counts all-to-all + a copy to pinned memory +
+ * an event; no host wait; up to 8 may be outstanding); every rank issues its calls on one communicator in the same order.
+ * coala_cache_fetch_distributed_bucketed_ahead(ticket) waits for that exchange's event (normally long complete) and runs the rest of
+ * the sequence -- ids, probe, fill rounds beside row rounds -- fully stream-ordered.  Rows and cache state equal the plain call's. */
+int coala_comm_counts_begin(coala_comm_t* c, const int64_t* counts_dev, void* stream, int64_t* ticket_out);
+int coala_cache_fetch_distributed_bucketed_ahead(coala_cache_t* h, coala_comm_t* c, float* out, const int64_t* idx, int64_t n,
+                                                 int64_t ticket, void* stream);
 /* Timing of the row exchange (all rounds of a fetch, HIP events on the communicator's stream; includes any wait for the fill of
  * a later round): enable = 1 / 0 switches it, -1 leaves it; out (nullable) receives the totals since the last reset. */
 typedef struct coala_comm_profile {

@@ -260,11 +260,12 @@ def test_native_fetch_inproc_ranks_match_oracle(hiplib, oracle, G, dim, cache_mb
         t.close()
 
 
-@pytest.mark.parametrize("G,dim,rounds", [(2, 256, 2), (4, 1024, 2), (8, 128, 3)])
-def test_native_bucketed_fetch_from_sampler_output(hiplib, oracle, G, dim, rounds):
+@pytest.mark.parametrize("G,dim,rounds,ahead", [(2, 256, 2, False), (4, 1024, 2, False), (8, 128, 3, False), (3, 512, 2, True), (8, 1024, 4, True)])
+def test_native_bucketed_fetch_from_sampler_output(hiplib, oracle, G, dim, rounds, ahead):
     """f-1 end to end: NeighborSampler(bucket_by_owner=G) -> coala_cache_fetch_distributed_bucketed on G in-process ranks (no routing
     pass, rows received in place, own bucket gathered in place): delivered rows, owner counters and tag tables == orc_dist_fetch
-    fed with the same (bucketed) id lists."""
+    fed with the same (bucketed) id lists.  ahead = True: the count exchange of step t+1 is issued (on a second stream, behind the
+    sampler) BEFORE the fetch of step t, which then runs without a host synchronisation (coala_comm_counts_begin / _ahead)."""
     import ctypes as C
     import threading
     import torch
@@ -290,13 +291,29 @@ def test_native_bucketed_fetch_from_sampler_output(hiplib, oracle, G, dim, round
         try:
             torch.cuda.set_device(0)
             stream = torch.cuda.Stream()
+            side = torch.cuda.Stream()
+
+            def sample(step):
+                seeds = torch.randperm(num_rows, generator=torch.Generator().manual_seed(100 * step + r))[:64].cuda()
+                if not ahead:
+                    return samplers[r].sample(graphs[r], seeds), None
+                with torch.cuda.stream(side):   # sampler + count exchange on their own stream, ahead of the fetch that uses them
+                    smp = samplers[r].sample(graphs[r], seeds)
+                    ticket = exs[r].counts_begin(smp[2][0].owner_counts.data_ptr())
+                    ev = torch.cuda.Event()
+                    ev.record()
+                torch.cuda.current_stream().wait_event(ev)
+                return smp, ticket
+
             with torch.cuda.stream(stream):
+                nxt = sample(0)
                 for step in range(steps):
-                    seeds = torch.randperm(num_rows, generator=torch.Generator().manual_seed(100 * step + r))[:64].cuda()
-                    input_nodes, _, blocks = samplers[r].sample(graphs[r], seeds)
+                    (input_nodes, _, blocks), ticket = nxt
+                    if step + 1 < steps:
+                        nxt = sample(step + 1)          # ahead: its count exchange goes out before this step's fetch
                     n = input_nodes.numel()
                     out = torch.full((n, dim), -9.0, dtype=torch.float32, device="cuda")
-                    exs[r].fetch_bucketed(caches[r], out.data_ptr(), input_nodes.data_ptr(), n, blocks[0].owner_counts.data_ptr())
+                    exs[r].fetch_bucketed(caches[r], out.data_ptr(), input_nodes.data_ptr(), n, blocks[0].owner_counts.data_ptr(), ticket=ticket)
                     stream.synchronize()
                     got[step][r] = out.cpu().numpy()
                     ids_seen[step][r] = input_nodes.cpu().numpy()

@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--fanout", type=str, default="5,5")
     ap.add_argument("--steps", type=int, default=600)
     ap.add_argument("--measure-from", type=int, default=300, help="steps before this one warm the caches")
+    ap.add_argument("--counts-ahead", action="store_true", help="partitioned mode: the count exchange of step t+1 goes out (sampler stream) before "
+                                                                 "the fetch of step t, which then has no host synchronisation")
     args = ap.parse_args()
     G, dim, fan = args.ranks, args.dim, [int(f) for f in args.fanout.split(",")]
     torch.cuda.set_device(0)
@@ -69,8 +71,24 @@ def main():
             try:
                 torch.cuda.set_device(0)
                 stream = torch.cuda.Stream()
+                side = torch.cuda.Stream()
                 gpu_ms, rows_n, checked = 0.0, 0, 0
+
+                def sample(step):
+                    lo = ((step % spe) * G + r) * args.batch  # rank r takes the r-th batch of the global batch
+                    seeds = train[lo: lo + args.batch].cuda()
+                    if not (part and args.counts_ahead):
+                        return samplers[r].sample(graphs[r], seeds, step=step), None
+                    with torch.cuda.stream(side):
+                        smp = samplers[r].sample(graphs[r], seeds, step=step)
+                        tk = exs[r].counts_begin(smp[2][0].owner_counts.data_ptr())
+                        ev = torch.cuda.Event()
+                        ev.record()
+                    torch.cuda.current_stream().wait_event(ev)
+                    return smp, tk
+
                 with torch.cuda.stream(stream):
+                    nxt = sample(0)
                     for step in range(args.steps):
                         if step == args.measure_from:
                             stream.synchronize()
@@ -78,14 +96,15 @@ def main():
                             caches[r].stats(reset=True)
                             bar.wait()
                             t0 = time.perf_counter()
-                        lo = ((step % spe) * G + r) * args.batch  # rank r takes the r-th batch of the global batch
-                        ids, _, blocks = samplers[r].sample(graphs[r], train[lo: lo + args.batch].cuda(), step=step)
+                        (ids, _, blocks), tk = nxt
+                        if step + 1 < args.steps:
+                            nxt = sample(step + 1)
                         n = ids.numel()
                         feat = torch.empty((n, dim), dtype=torch.float32, device="cuda")
                         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                         a.record()
                         if part:
-                            exs[r].fetch_bucketed(caches[r], feat.data_ptr(), ids.data_ptr(), n, blocks[0].owner_counts.data_ptr())
+                            exs[r].fetch_bucketed(caches[r], feat.data_ptr(), ids.data_ptr(), n, blocks[0].owner_counts.data_ptr(), ticket=tk)
                         else:
                             caches[r].read_feature(feat.data_ptr(), ids.data_ptr(), n)
                         b.record()

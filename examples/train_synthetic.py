@@ -44,7 +44,13 @@ def main():
     ap.add_argument("--path", type=str, default=None, help="dataset root in the reference's layout (default: synthetic data)")
     ap.add_argument("--data", type=str, default="IGB", choices=["IGB", "OGB", "flat"])
     ap.add_argument("--dataset_size", type=str, default="experimental")
+    # accepted so that the reference's command lines (examples/4GB_script.sh, Cache_compare_script.sh, Distribution_compare_script.sh) run as they are
+    ap.add_argument("--num_layers", type=int, default=None, help="must equal the number of fan-outs when given")
+    ap.add_argument("--feat_cpu", action="store_true", help="features in pinned host memory: always the case here (the NVMe tier is out of scope)")
+    ap.add_argument("--model_type", type=str, default="sage", choices=["sage"], help="the harness model; the reference's GAT is dense compute outside the path")
     args = ap.parse_args()
+    if args.num_layers is not None and args.num_layers != len(args.fan_out.split(",")) and args.num_layers != 2:
+        ap.error("--num_layers does not match --fan_out")   # (the reference's own scripts pass --num_layers 2 with a 3-entry fan-out: tolerated)
 
     local_rank = int(os.environ.get("LOCAL_RANK", os.environ.get("SLURM_LOCALID", 0)))
     node_rank = int(os.environ.get("SLURM_NODEID", 0))

@@ -400,7 +400,10 @@ def test_example_training_script_on_a_dataset_directory(tmp_path):
     np.save(cites / "edge_index.npy", np.stack([rng.integers(0, n, size=e), rng.integers(0, n, size=e)], axis=1).astype(np.int64))
     root = os.path.dirname(HERE)
     out = subprocess.run([sys.executable, os.path.join(root, "examples", "train_synthetic.py"), "--path", str(tmp_path), "--data", "IGB",
-                          "--dataset_size", "small", "--batch_size", "128", "--epochs", "1", "--cache_size", "2"],
+                          "--dataset_size", "small", "--batch_size", "128", "--epochs", "1", "--cache_size", "2",
+                          # the rest as in the reference's launch scripts (examples/Distribution_compare_script.sh:27)
+                          "--fan_out", "10,5,5", "--num_layers", "2", "--feat_cpu", "--model_type", "sage", "--cache_backend", "isolated",
+                          "--distribution", "baseline"],
                          capture_output=True, text=True, timeout=600, env=dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"))
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     assert out.stdout.count("Epoch Time:") == 1 and "GPU hit ratio:" in out.stdout and "final loss" in out.stdout and "Test Acc" in out.stdout

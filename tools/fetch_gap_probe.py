@@ -32,6 +32,7 @@ def keep(wait):  # keep every (start, end) event pair instead of folding them aw
 mgr._fold_events = keep
 model = SageMean(dim, 128, 19).cuda(); opt = torch.optim.Adam(model.parameters(), 1e-3, fused=True); lossf = torch.nn.CrossEntropyLoss()
 train = os.environ.get("TRAIN", "1") == "1"
+import gc; gc.collect(); gc.freeze()   # a full collection of the interpreter inside the loop is a 100 ms hole of its own
 torch.cuda.synchronize(); t0 = time.perf_counter(); n = 0
 for inp, sd, blocks, feat in loader:
     if train:

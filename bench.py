@@ -33,6 +33,24 @@ for _p in (ROOT, PKG):
 # HIP runtime starts; a value already in the environment wins.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
+
+def _bind_numa():
+    """Before the HIP runtime exists (its helper threads inherit the mask) and before anything is pinned: run this rank on the NUMA
+    node of its GPU, so that its shard of the cold tier is allocated next to the link that reads it (COALA_GNN/numa.py; COALA_NUMA=off
+    leaves the process where the launcher put it).  numa.py is loaded by path: importing the package would import torch first."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("coala_numa", os.path.join(PKG, "COALA_GNN", "numa.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    dev = 0 if os.environ.get("COALA_BENCH_SINGLE_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
+    try:
+        return mod, mod.bind_to_device_node(dev)
+    except Exception as e:  # noqa: BLE001 -- placement is an optimisation: never the reason a run does not start
+        return mod, {"applied": False, "why": repr(e)}
+
+
+_NUMA, NUMA_INFO = _bind_numa()
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -52,9 +70,11 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--cache-mb", type=int, default=4096)
     ap.add_argument("--avg-degree", type=float, default=12.0)
-    ap.add_argument("--counts-ahead", action="store_true",
-                    help="N>1, native exchange: the count exchange of minibatch s+1 is issued (side stream) before the fetch of minibatch s, "
-                         "which then runs without its host synchronisation (coala_comm_counts_begin); off by default")
+    ap.add_argument("--counts-ahead", dest="counts_ahead", action="store_true", default=True,
+                    help="N>1, native exchange, sampler-bucketed ids (the default there): the count exchange of minibatch s+1 is issued (side "
+                         "stream) before the fetch of minibatch s, which then runs without its host synchronisation (coala_comm_counts_begin)")
+    ap.add_argument("--no-counts-ahead", dest="counts_ahead", action="store_false",
+                    help="N>1: every fetch exchanges its own counts and reads them back synchronously (one host wait per minibatch)")
     ap.add_argument("--rounds", type=int, default=0, help="N>1: row-exchange rounds per fetch (1..8); default: measured during the warm-up")
     ap.add_argument("--no-tune-rounds", action="store_true", help="N>1: keep the default number of exchange rounds (2) instead of measuring")
     ap.add_argument("--prewarm", type=int, default=400, help="untimed minibatches that bring the cache to steady state")
@@ -68,10 +88,13 @@ def parse_args():
     ap.add_argument("--epoch-steps", type=int, default=-1,
                     help="end-to-end leg (loader + GraphSAGE step): -1 = one FULL epoch per mode (measured, not extrapolated), "
                          "k > 0 = k steps extrapolated to an epoch, 0 = skip")
-    ap.add_argument("--epoch-prefetch-multi", dest="epoch_prefetch_multi", action="store_true", default=True,
-                    help="N>1: after the serial epoch leg has succeeded, also run it with the prefetching loader (default)")
+    ap.add_argument("--epoch-prefetch-multi", dest="epoch_prefetch_multi", action="store_true", default=False,
+                    help="N>1: after the serial epoch leg has succeeded, also run it with the prefetching loader (producer thread).  "
+                         "OFF by default: the producer thread then issues the exchange's RCCL collectives while the consumer thread "
+                         "issues DDP's all-reduce on torch's communicator -- two communicators driven from two host threads with no "
+                         "cross-rank launch order, which RCCL documents as a deadlock risk and which has never run on two physical GPUs")
     ap.add_argument("--no-epoch-prefetch-multi", dest="epoch_prefetch_multi", action="store_false",
-                    help="N>1: serial loader only (with prefetch the exchange's RCCL communicator and DDP's are driven from two host threads)")
+                    help="N>1: serial loader only (the default)")
     ap.add_argument("--epoch-timeout", type=float, default=240.0,
                     help="N>1: seconds after which the extra legs are abandoned: the JSON line is printed with an error field and every "
                          "rank exits with code 3")
@@ -82,8 +105,10 @@ def parse_args():
                     help="N=1: skip the extra leg that measures colour-affinity seed routing against baseline striping with two domains on this GPU "
                          "(tools/color_affinity_probe.py, a child process)")
     ap.add_argument("--no-fanout-leg", action="store_true", help="skip the extra fan-out 10,10 leg (BASELINE.json configs[2] batch shape)")
-    ap.add_argument("--cold-tier", type=str, default="host", choices=["host", "hbm"],
-                    help="host: pinned host memory, zero-copy over PCIe (the workload BASELINE.json names). hbm: the whole table "
+    ap.add_argument("--cold-tier", type=str, default="host", choices=["host", "shm", "hbm"],
+                    help="host: pinned host memory (hipHostMalloc), zero-copy over PCIe (the workload BASELINE.json names). shm: the "
+                         "reference's own kind -- ONE POSIX shm segment per machine, mapped and hipHostRegister'ed by every rank through "
+                         "Shared_UVA_Tensor_Manager (shared_UVA.cuh:60-100); whole table, not owner-partitioned. hbm: the whole table "
                          "resident in this GPU's 288 GB HBM (not the headline configuration; MI355X placement data point)")
     ap.add_argument("--seed", type=int, default=0)
     return ap.parse_args()
@@ -202,6 +227,23 @@ def main():
     from COALA_GNN.sampler import NeighborSampler
 
     backend = args.backend or ("isolated" if world == 1 else "nccl")
+    # N = 1 with a distributed backend = the dress rehearsal of the multi-GPU run on one GPU: a torch.distributed world of ONE rank with
+    # RCCL for GPU tensors (DDP's all-reduce in the epoch leg goes through torch's RCCL communicator), the fused native exchange on its
+    # OWN one-rank RCCL communicator, sampler-bucketed ids, the count exchange issued ahead -- every code path of N > 1 except bytes on
+    # a link.  (The driver's GPU tests run it: RCCL start-up and the coexistence of the two communicators are exercised on every round.)
+    rehearsal = world == 1 and backend in ("nccl", "nvshmem") and not single_dev
+    if rehearsal:
+        import socket
+        if "MASTER_PORT" not in os.environ:
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            sk.close()
+        dist.init_process_group("cpu:gloo,cuda:nccl", rank=0, world_size=1)
+        if args.exchange is None:
+            args.exchange = "native"
+        os.environ["COALA_EXCHANGE"] = args.exchange      # the managers of the later legs (loader, fan-out 10,10) follow
+    args.rehearsal = rehearsal
     comm = MPI_Comm_Manager(0, backend="gloo" if single_dev else None)   # one machine: every rank in domain 0
     comm.device_index = dev_index
     comm.initialize_nested_process_group(backend)
@@ -252,6 +294,35 @@ def _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, dev
         else:
             table = _HbmTable(args.rows, args.dim)
         host_array = None
+    elif args.cold_tier == "shm":
+        # the reference-API cold tier: what a user following INTEGRATION.md hands to `sim_buf`
+        from COALA_GNN import Shared_UVA_Tensor_Manager
+
+        class _ShmTable:
+            def __init__(self, rows, dim):
+                t_reg = time.perf_counter()
+                self.mgr = Shared_UVA_Tensor_Manager(comm, f"/coala_bench_feat_{os.environ.get('MASTER_PORT', '0')}", rows * dim * 4)
+                self.register_s = time.perf_counter() - t_reg
+                self.array = self.mgr.get_host_array(np.float32, (rows, dim))
+                self.cpu_tensor = torch.from_numpy(self.array)
+                self.alias = self.mgr.get_tensor(torch.float32, device, (rows, dim))
+                self.device_ptr, self.host_ptr = self.mgr.device_ptr, self.mgr.host_ptr
+
+            def data_ptr(self):
+                return self.device_ptr
+
+            def close(self):
+                self.alias = self.cpu_tensor = self.array = None
+                self.mgr.cleanup()
+        table = _ShmTable(args.rows, args.dim)
+        log(f"shm segment of {nbytes / 1e9:.2f} GB created/mapped + hipHostRegister'ed in {table.register_s:.2f}s")
+        if comm.local_rank == 0:   # local rank 0 writes the table through its device alias (write_np_array_gpu's way, Shared_Tensor.py:164-179)
+            for lo in range(0, args.rows, 1 << 18):
+                hi = min(args.rows, lo + (1 << 18))
+                feature_rows_torch(torch.arange(lo, hi, dtype=torch.int64, device=device), args.dim, args.seed, out=table.alias[lo:hi])
+            torch.cuda.synchronize()
+        comm.local_comm.Barrier()
+        host_array = table.array
     elif world == 1 or backend == "isolated":
         # the whole table, private to this rank (an isolated cache may read any row).  If the host cannot pin that much
         # memory, the node count is scaled down and the factor reported.
@@ -281,6 +352,18 @@ def _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, dev
         nbytes = local_rows * args.dim * 4
     sim_ptr_owner = table
     log(f"cold table {nbytes / 1e9:.2f} GB pinned + filled in {time.time() - t0:.1f}s")
+    # where this rank's cold tier really is: the node the kernel reports for its first and its middle page (move_pages query), next to
+    # the GPU's node and what the binding did
+    numa_me = dict(NUMA_INFO)
+    hp = getattr(table, "host_ptr", None)
+    if hp:
+        numa_me["cold_tier_node_first_page"] = _NUMA.node_of_memory(hp)
+        numa_me["cold_tier_node_middle_page"] = _NUMA.node_of_memory(hp + nbytes // 2)
+    if world > 1:
+        numa_all = [None] * world
+        dist.all_gather_object(numa_all, numa_me, group=comm.local_gloo_gather)
+    else:
+        numa_all = [numa_me]
 
     # ---------------------------------------------------------------- graph + train ids
     t0 = time.time()
@@ -291,7 +374,7 @@ def _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, dev
     steps_per_epoch = n_train // (args.batch * world) - 1  # COALA_GNN_DataLoader.py:141
     # N>1 over the native exchange: the sampler delivers the input nodes already bucketed by owner, so the fetch needs no routing
     # pass and no un-permute (rows are received in place)
-    bucket = world if (world > 1 and backend != "isolated") else 0
+    bucket = world if ((world > 1 or args.rehearsal) and backend != "isolated") else 0
     sampler = NeighborSampler(fanout, seed=args.seed, bucket_by_owner=bucket)
     graph = sampler.make_graph(indptr, indices)
     log(f"graph {args.rows} nodes / {indices.numel()} edges built in {time.time() - t0:.1f}s")
@@ -406,7 +489,7 @@ def _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, dev
         xch.reset_profile()
         xch.profile = True
 
-    ahead = bool(args.counts_ahead and world > 1 and bucket and hasattr(manager.exchange, "counts_begin") and args.mode == "minibatch")
+    ahead = bool(args.counts_ahead and (world > 1 or args.rehearsal) and bucket and hasattr(manager.exchange, "counts_begin") and args.mode == "minibatch")
     if ahead:   # the loaders' pipeline (counts_ahead=True) on pre-sampled minibatches: exchange s+1's counts, then fetch s
         side = torch.cuda.Stream(device=device)
 
@@ -490,7 +573,8 @@ def _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, dev
     # algorithmic bytes per launch (DESIGN.md "Kernels"): every probed row reads its int64 id and one 32x8 B tag set;
     # every hit additionally reads a dim*4 line and writes a dim*4 output row  (B_row = 2*dim*4+8+256)
     launches = max(prof.gather_launches, 1)
-    alg_bytes = prof.gather_rows * (8 + 256) + prof.gather_hits * (2 * args.dim * 4)
+    tag_set_bytes = int(cache.geometry().tag_set_bytes)   # 128: 32-bit tags (every id < 2^32), 256: the reference's 64-bit tags
+    alg_bytes = prof.gather_rows * (8 + tag_set_bytes) + prof.gather_hits * (2 * args.dim * 4)
     k_ms = prof.gather_ms / launches
     achieved = (alg_bytes / launches) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     roofline = {
@@ -501,7 +585,7 @@ def _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, dev
         "separate_event_bracket_would_add_us": round(prof.event_overhead_us, 2),
         "launches": int(prof.gather_launches),
         "rows_per_launch": round(prof.gather_rows / launches, 1), "hits_per_launch": round(prof.gather_hits / launches, 1),
-        "alg_bytes_per_launch": int(alg_bytes / launches),
+        "alg_bytes_per_launch": int(alg_bytes / launches), "alg_bytes_per_row": f"8 (id) + {tag_set_bytes} (one set of 32 tags) + 2 x {args.dim * 4} per hit",
         "cold_fill_avg_us": round(prof.fill_ms / max(prof.fill_launches, 1) * 1e3, 2),
     }
 
@@ -523,7 +607,7 @@ def _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, dev
         h2, m2, _ = cache.stats()
         p2 = cache.profile()
         l2 = max(p2.gather_launches, 1)
-        b2 = p2.gather_rows * (8 + 256) + p2.gather_hits * (2 * args.dim * 4)
+        b2 = p2.gather_rows * (8 + tag_set_bytes) + p2.gather_hits * (2 * args.dim * 4)
         us2 = p2.gather_ms / l2 * 1e3
         ach2 = (b2 / l2) / (us2 * 1e-6) / 1e9 if us2 > 0 else 0.0
         roofline_allhit = {"bound": "hbm", "kernel": "probe_gather_kernel", "achieved": round(ach2, 1), "peak": HBM_PEAK_GBS,
@@ -539,7 +623,7 @@ def _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, dev
     fill_bytes = prof.fill_rows * args.dim * 4 / fill_launches
     pcie_peak = 63.0  # GB/s, PCIe Gen5 x16 spec (/opt/skills/guides/MI355X_MICROARCH.md "Host link")
     roofline_cold = None
-    if args.cold_tier == "host" and prof.fill_rows:
+    if args.cold_tier in ("host", "shm") and prof.fill_rows:
         ach = fill_bytes / (fill_us * 1e-6) / 1e9 if fill_us > 0 else 0.0
         roofline_cold = {"bound": "pcie", "kernel": "miss_fill_kernel", "achieved": round(ach, 2), "peak": pcie_peak, "unit": "GB/s",
                          "frac": round(ach / pcie_peak, 4), "avg_launch_us": round(fill_us, 2),
@@ -562,12 +646,19 @@ def _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, dev
                        "rows_per_step_per_gpu": round(rows_all / world / args.steps, 1),
                        "hit_ratio": round(hit_all / max(hit_all + miss_all, 1.0), 4),
                        "cache_backend": backend, **({"TEST_HOOK_single_device": True} if single_dev else {}),
-                       "exchange_transport": (exchange_note or getattr(manager, "exchange_kind", None)) if world > 1 else None,
+                       "exchange_transport": (exchange_note or getattr(manager, "exchange_kind", None)) if (world > 1 or args.rehearsal) else None,
+                       # what RCCL itself reports for the exchange's communicator (ncclCommCount), not the number it was created with
                        "rccl_ranks": (getattr(manager.exchange, "rccl_ranks", None) or
-                                      (dist.get_world_size(comm.nccl_cache_gather) if not single_dev else None)) if world > 1 else None,
+                                      (dist.get_world_size(comm.nccl_cache_gather) if (not single_dev and comm.nccl_cache_gather is not None) else None))
+                       if (world > 1 or args.rehearsal) else None,
+                       **({"rccl_rehearsal_one_rank": True} if args.rehearsal else {}),
                        "exchange_rounds": rounds_probe, "counts_ahead": bool(ahead), "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "input_nodes": "bucketed by owner by the sampler (no routing pass, rows received in place)" if bucket else "sampler order",
-                       "parity_check": "rows of one warm-up minibatch == synthetic table formula, bit-exact, on every rank", "cold_tier": "HBM" if args.cold_tier == "hbm" else ("pinned host, owner-partitioned" if cold_partitioned else "pinned host"),
+                       "parity_check": "rows of one warm-up minibatch == synthetic table formula, bit-exact, on every rank", "cold_tier": {"hbm": "HBM", "shm": "POSIX shm + hipHostRegister, one segment mapped by every rank (Shared_UVA_Tensor_Manager)"}.get(
+                           args.cold_tier, "pinned host (hipHostMalloc), owner-partitioned" if cold_partitioned else "pinned host (hipHostMalloc)"),
+                       "cold_tier_register_s": round(getattr(table, "register_s", 0.0), 2) or None,
+                       "cold_tier_numa_node": [d.get("cold_tier_node_middle_page") for d in numa_all],
+                       "numa": [{k: d.get(k) for k in ("mode", "gpu_numa_node", "bound_node", "cpus", "applied", "why") if d.get(k) is not None} for d in numa_all],
                        "prewarm_steps": args.prewarm, "rows_scale_factor": rows_scale,
                        "steps_per_epoch": steps_per_epoch,
                        "epoch_time_s_fetch_only_extrapolated": round(ms_per_step * steps_per_epoch / 1e3, 2)},
@@ -619,6 +710,8 @@ def _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, dev
     if world > 1:
         guard.close()
         comm.destroy_process_group()
+    elif args.rehearsal and dist.is_initialized():
+        dist.destroy_process_group()
 
 
 def run_color_affinity_leg(timeout_s=400):
@@ -649,7 +742,7 @@ def run_fanout_leg(args, comm, graph, table, device, fanout, backend, cold_parti
     """Fetch-only rate of the same table / graph / cache size at another fan-out (own cache handle, own sampler)."""
     from COALA_GNN.COALA_GNN_Manager import COALA_GNN_Manager
     from COALA_GNN.sampler import NeighborSampler
-    smp = NeighborSampler(fanout, seed=args.seed, bucket_by_owner=world if (world > 1 and backend != "isolated") else 0)
+    smp = NeighborSampler(fanout, seed=args.seed, bucket_by_owner=world if ((world > 1 or getattr(args, "rehearsal", False)) and backend != "isolated") else 0)
     mgr = COALA_GNN_Manager(node_distributor=None, num_ssds=1, page_size=args.dim * 4, num_elems=1024, ssd_read_offset=0,
                             cache_size=args.cache_mb, batch_size=args.batch, fan_out=fanout, dim=args.dim,
                             MPI_comm_manager=comm, device=device, cache_backend=backend, sim_buf=table, num_rows=args.rows,
@@ -715,7 +808,7 @@ def run_epoch_leg(args, comm, graph, sampler, table, device, fanout, steps_per_e
     from COALA_GNN.synthetic import block_colors
     out = {} if out is None else out
     out.update({"model": "GraphSAGE 2-layer mean, hidden 128, 19 classes, Adam (torch; out of scope, harness only)"
-                         + (", DistributedDataParallel" if world > 1 else ""),
+                         + (", DistributedDataParallel" if (world > 1 or getattr(args, "rehearsal", False)) else ""),
                 "per_step": "distribute + sample + fetch_feature + forward/backward/optimizer", "steps_per_epoch": steps_per_epoch,
                 "cache_backend": backend})
     # serial first: at N>1 the prefetching loader (exchange and DDP collectives issued from two host threads) only runs behind
@@ -728,7 +821,8 @@ def run_epoch_leg(args, comm, graph, sampler, table, device, fanout, steps_per_e
     if world > 1 and not args.epoch_prefetch_multi:
         modes = modes[:1]
         out["prefetch"] = None
-        out["note"] = "--no-epoch-prefetch-multi: serial loader only"
+        out["note"] = ("serial loader only at N>1 (one host thread issues the exchange's and DDP's collectives in one order on every rank); "
+                       "--epoch-prefetch-multi adds the producer-thread loader")
     inject = os.environ.get("COALA_BENCH_INJECT_FAIL", "")  # test hook "rank:leg": that rank raises at the start of that leg
 
     def across_ranks(secs, nodes):
@@ -774,7 +868,7 @@ def run_epoch_leg(args, comm, graph, sampler, table, device, fanout, steps_per_e
                                           prefetch=prefetch, cold_partitioned=cold_partitioned)
             torch.manual_seed(0)  # identical initial weights on every rank
             model = SageMean(args.dim, 128, 19).to(device)
-            if world > 1:
+            if world > 1 or getattr(args, "rehearsal", False):
                 # the development hook (all ranks on one GPU) cannot use RCCL: gradients go through a gloo group there
                 pg = dist.new_group(backend="gloo") if single_dev else None
                 model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev_index], process_group=pg)
@@ -864,12 +958,22 @@ def run_cpu_baseline(args, host_array, batches, fanout, graph=None, seeds_for=No
         for s in range(k):
             O.sample_blocks(ip, ix, seeds_for(s).cpu().numpy(), list(reversed(fanout)), args.seed, s)
         res["sampler_twin_one_core_ms_per_minibatch"] = round((time.perf_counter() - t0) / k * 1e3, 3)
+        # ... and on all host cores this job may use (OpenMP: the draws over the destination nodes -- the counter-based RNG makes the
+        # result independent of the thread count -- and the first-appearance compaction as CAS inserts + a prefix sum)
+        cores = len(os.sched_getaffinity(0))
+        O.sample_blocks(ip, ix, seeds_for(0).cpu().numpy(), list(reversed(fanout)), args.seed, 0, threads=cores)   # thread pool start-up
+        t0 = time.perf_counter()
+        for s in range(k):
+            O.sample_blocks(ip, ix, seeds_for(s).cpu().numpy(), list(reversed(fanout)), args.seed, s, threads=cores)
+        res["sampler_twin_all_cores"] = {"ms_per_minibatch": round((time.perf_counter() - t0) / k * 1e3, 3), "cores": cores,
+                                         "what": "OpenMP: draws over destination nodes per layer, compaction by CAS inserts + prefix sum; same blocks as one core"}
     # extrapolated epoch of the CPU path = steps x (CPU sampler + best CPU gather), no training step
     steps_per_epoch = int(0.6 * args.rows) // args.batch - 1
     ms_oracle = dt / max(i, 1) * 1e3
     ms_gather = min(ms_oracle, res["index_select_all_cores"].get("ms_per_minibatch", ms_oracle))
     res["epoch_time_s_extrapolated_sampler_plus_gather"] = round(
-        steps_per_epoch * (ms_gather + res.get("sampler_twin_one_core_ms_per_minibatch", 0.0)) / 1e3, 1)
+        steps_per_epoch * (ms_gather + min(res.get("sampler_twin_one_core_ms_per_minibatch", 0.0),
+                                           res.get("sampler_twin_all_cores", {}).get("ms_per_minibatch", 1e9))) / 1e3, 1)
     return res
 
 

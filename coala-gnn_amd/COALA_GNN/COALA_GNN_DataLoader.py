@@ -135,17 +135,19 @@ class SSD_INFO(object):  # COALA_GNN_DataLoader.py:80-90
 class COALA_GNN_DataLoader(torch.utils.data.DataLoader):
     def __init__(self, SSD_info, node_distributor, graph, graph_sampler, batch_size, dim, fan_out, cache_size, device,
                  refresh_counter=10, cache_backend="nvshmem", sim_buf=None, shuffle=False, num_rows=None, profile=False,
-                 prefetch=0, cold_partitioned=False, sync_fetch=False, counts_ahead=False):
+                 prefetch=0, cold_partitioned=False, sync_fetch=False, counts_ahead=None):
         # like the reference, torch's DataLoader.__init__ is never called: this is a plain iterator
         # prefetch = 0: the reference's strictly serial __next__ (:149-167).  prefetch = k > 0: a producer thread runs
         # distribute -> sample -> fetch for the next k steps on its own HIP stream while the consumer trains (SURVEY f-2).
         # sync_fetch = True: the reference's fetch_feature, which returns only when the rows are in place.  False (default):
         # the fetch is only ENQUEUED on the current stream -- the training step that follows is ordered behind it by the stream,
         # and its launch overhead (about 1 ms of host time for the GraphSAGE step) overlaps the fetch instead of following it.
-        # counts_ahead = True (opt-in; native exchange + a sampler that buckets by owner): the count exchange of a distributed fetch is
-        # issued right behind the sample, two steps before its fetch, so the fetch itself needs no host synchronisation
-        # (coala_comm_counts_begin).  Every rank of the cache group must use the same setting.
-        self.counts_ahead = bool(counts_ahead)
+        # counts_ahead (native exchange + a sampler that buckets by owner; None = on whenever both are there): the count exchange of a
+        # distributed fetch is issued right behind the sample, two steps before its fetch, so the fetch itself needs no host
+        # synchronisation (coala_comm_counts_begin).  A fetch whose ticket has left the communicator's ring of pending count
+        # exchanges falls back to the synchronous count (NativeExchange.fetch_bucketed) -- every rank makes the same calls in the same
+        # order, so every rank falls back together.  Every rank of the cache group must use the same setting.
+        self.counts_ahead = counts_ahead
         self.prefetch = int(prefetch)
         self._producer = None
         self._queue = None
@@ -174,6 +176,9 @@ class COALA_GNN_DataLoader(torch.utils.data.DataLoader):
         self.COALA_GNN_Manager.sync_on_return = bool(sync_fetch)
         # the native sampler is stream-aware (it launches on torch's current stream); a foreign sampler keeps the caller's stream
         self._sample_on_side_stream = (not sync_fetch) and str(device).startswith("cuda") and getattr(graph_sampler, "stream_safe", False)
+        if self.counts_ahead is None:
+            self.counts_ahead = bool(getattr(graph_sampler, "bucket_by_owner", 0)) and hasattr(self.COALA_GNN_Manager.exchange, "counts_begin")
+        self.counts_ahead = bool(self.counts_ahead)
         self.scheduler = COALA_GNN_Node_Distribution_Scheduler(node_distributor=self.node_distributor,
                                                                ssd_gnn_manager=self.COALA_GNN_Manager,
                                                                refresh_counter=self.refresh_counter)

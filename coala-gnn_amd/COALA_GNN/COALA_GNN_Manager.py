@@ -294,7 +294,10 @@ class NativeExchange(object):
             _capi.check(self._lib.coala_comm_create(uid.data_ptr(), rank, world, int(device_index), C.byref(self._h)))
         if rounds is not None:
             _capi.check(self._lib.coala_comm_set_rounds(self._h, int(rounds)))
-        self.rccl_ranks = int(self._lib.coala_comm_size(self._h))
+        self.rccl_ranks = int(self._lib.coala_comm_size(self._h))   # as the transport counts them (ncclCommCount), not the number asked for
+        if self.rccl_ranks != world:
+            raise RuntimeError(f"the exchange's communicator reports {self.rccl_ranks} ranks, {world} expected: {_capi.last_error()}")
+        self._tickets = 0        # count exchanges issued ahead so far (tickets are consecutive)
         self.last_send_counts = self.last_recv_counts = None
         self._profile = False
 
@@ -341,12 +344,15 @@ class NativeExchange(object):
         from COALA_GNN_Pybind import current_stream
         t = self._C.c_int64(-1)
         self._capi.check(self._lib.coala_comm_counts_begin(self._h, int(counts_ptr), current_stream(), self._C.byref(t)))
+        self._tickets = int(t.value) + 1
         return int(t.value)
 
     def fetch_bucketed(self, ops, out_ptr, idx_ptr, n, counts_ptr, ticket=None):
         """idx already bucketed by owner (NeighborSampler(bucket_by_owner=G)): no routing pass, rows received in place.
         ticket = a counts_begin of the same counts issued earlier: the fetch then runs without a host synchronisation."""
         from COALA_GNN_Pybind import current_stream, native
+        if ticket is not None and self._tickets - int(ticket) > self._capi.COUNTS_RING:
+            ticket = None   # its slot of the ring has been reused: exchange the counts again, synchronously (the same decision on every rank)
         if ticket is not None:
             self._capi.check(self._lib.coala_cache_fetch_distributed_bucketed_ahead(ops._h, self._h, int(out_ptr) or None, int(idx_ptr) or None,
                                                                                      int(n), int(ticket), current_stream()))

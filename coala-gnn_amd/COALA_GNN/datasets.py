@@ -84,12 +84,20 @@ def load_csc_arrays(graph_dir, num_nodes, device=None):
     return indptr, indices
 
 
-def load_labels_and_masks(label_path, num_nodes, layout):
+# IGB-full: only a prefix of the 269 M nodes carries labels (examples/ssd_gnn_dataloader.py:530-534)
+IGB_FULL_LABELLED = {19: 227130858, 2983: 157675969}
+
+
+def load_labels_and_masks(label_path, num_nodes, layout, dataset_size=None, num_classes=19):
     """-> (labels int64 [N] with -1 for OGB's unlabelled (NaN) nodes, train / val / test bool masks) by the reference's split rules:
-    the first 60 / next 20 / last 20 % of the node ids (IGB, :550-559), or of the labelled nodes (OGB, :809-843)."""
+    the first 60 / next 20 / last 20 % of the node ids (IGB, :550-559), of IGB-full's labelled prefix (:527-546), or of the labelled
+    nodes (OGB, :809-843).  IGB large / full keep their 19-class labels as a HEADERLESS float32 file (np.memmap, :381-387)."""
     labelled = None
     if os.path.exists(label_path):
-        raw = np.load(label_path).reshape(-1)
+        if layout == "IGB" and dataset_size in ("large", "full") and num_classes == 19:
+            raw = np.array(np.memmap(label_path, dtype=np.float32, mode="r", shape=(num_nodes,)))
+        else:
+            raw = np.load(label_path).reshape(-1)
         if np.issubdtype(raw.dtype, np.floating):
             nan = np.isnan(raw)
             if nan.any():
@@ -108,10 +116,13 @@ def load_labels_and_masks(label_path, num_nodes, layout):
         val_mask[pool[n_train: n_train + n_val]] = True
         test_mask[pool[n_train + n_val:]] = True
     else:
-        n_train, n_val = int(num_nodes * 0.6), int(num_nodes * 0.2)
+        pool_n = num_nodes
+        if layout == "IGB" and dataset_size == "full":   # the masks stop at the labelled prefix (:530-546)
+            pool_n = min(num_nodes, IGB_FULL_LABELLED[19 if num_classes == 19 else 2983])
+        n_train, n_val = int(pool_n * 0.6), int(pool_n * 0.2)
         train_mask[:n_train] = True
         val_mask[n_train: n_train + n_val] = True
-        test_mask[n_train + n_val:] = True
+        test_mask[n_train + n_val: pool_n] = True
     return labels, train_mask, val_mask, test_mask
 
 
@@ -141,7 +152,7 @@ class SharedCSCDataset(object):
                 host[lo: lo + step] = feat_mm[lo: lo + step]
         comm_manager.local_comm.Barrier()
         indptr, indices = load_csc_arrays(paths["graph_dir"], self.num_nodes, device=device)
-        labels, train_mask, val_mask, test_mask = load_labels_and_masks(paths["label"], self.num_nodes, layout)
+        labels, train_mask, val_mask, test_mask = load_labels_and_masks(paths["label"], self.num_nodes, layout, dataset_size, num_classes)
         nd = {"label": labels.to(device), "labels": labels.to(device), "train_mask": train_mask, "val_mask": val_mask,
               "test_mask": test_mask}
         self.graph = CSCGraph(indptr.to(device), indices.to(device), ndata=nd)       # :523 (HBM instead of UVA)

@@ -174,7 +174,7 @@ class Node_distributor_pybind:
 # ------------------------------------------------------------------------------------------------------------ caches
 class _CacheBase:
     def _create(self, ctrls, node_distributer, g_rank, n_gpus, cache_size, sim_b, *, distributed, rank, num_rows,
-                profile=False, sync=True, max_batch=0, cold_partitioned=False):
+                profile=False, sync=True, max_batch=0, cold_partitioned=False, tag64=False):
         if not isinstance(ctrls, SSD_GNN_SSD_Controllers):
             raise TypeError("first argument must be SSD_GNN_SSD_Controllers")
         if int(sim_b) == 0:
@@ -188,7 +188,8 @@ class _CacheBase:
         cfg.rank = int(rank)
         cfg.global_rank = int(g_rank)
         cfg.flags = (_capi.FLAG_SYNC if sync else 0) | (_capi.FLAG_DISTRIBUTED if distributed else 0) | (
-            _capi.FLAG_PROFILE if profile else 0) | (_capi.FLAG_COLD_PARTITIONED if cold_partitioned else 0)
+            _capi.FLAG_PROFILE if profile else 0) | (_capi.FLAG_COLD_PARTITIONED if cold_partitioned else 0) | (
+            _capi.FLAG_TAG64 if tag64 else 0)
         cfg.cold_table = int(sim_b)
         color_ptr, num_colors, entries = 0, 0, 0
         if node_distributer is not None:
@@ -332,13 +333,14 @@ class _CacheBase:
 class Isolated_Cache(_CacheBase):
     """ssd_gnn_cache.cuh:201-371.  Isolated_Cache(ctrls, node_distributor, g_rank, n_gpus, cache_MB, sim_buf_ptr).
 
-    Keyword-only extras: num_rows (rows of the feature table when the distributor has no colour file), profile, sync."""
+    Keyword-only extras: num_rows (rows of the feature table when the distributor has no colour file), profile, sync,
+    tag64 (keep the reference's 64-bit tags; default: 32-bit tags whenever num_rows < 2^32 -- one 128-B line per set)."""
 
     def __init__(self, SSD_Controllers, node_distributer, g_rank, n_gpus, cache_size, sim_b, *, num_rows=None,
-                 profile=False, sync=True, max_batch=0, rank=None, cold_partitioned=False):
+                 profile=False, sync=True, max_batch=0, rank=None, cold_partitioned=False, tag64=False):
         self._create(SSD_Controllers, node_distributer, g_rank, n_gpus, cache_size, sim_b, distributed=False,
                      rank=SSD_Controllers.cudaDevice % max(int(n_gpus), 1) if rank is None else rank, num_rows=num_rows,
-                     profile=profile, sync=sync, max_batch=max_batch, cold_partitioned=cold_partitioned)
+                     profile=profile, sync=sync, max_batch=max_batch, cold_partitioned=cold_partitioned, tag64=tag64)
 
     def read_feature(self, i_return_tensor_ptr, i_index_ptr, max_index):  # ssd_gnn_cache.cuh:255-268
         self._read(i_return_tensor_ptr, i_index_ptr, max_index)
@@ -373,10 +375,10 @@ class SSD_GNN_NVSHMEM_Cache(_CacheBase):
     (nvshmem_cache.h:347).  The NVSHMEM one-sided transport is replaced by an exchange hook: see attach_exchange()."""
 
     def __init__(self, SSD_Controllers, node_distributer, g_rank, n_gpus, cache_size, sim_b, *, num_rows=None,
-                 profile=False, sync=True, max_batch=0, rank=None, cold_partitioned=False):
+                 profile=False, sync=True, max_batch=0, rank=None, cold_partitioned=False, tag64=False):
         self._create(SSD_Controllers, node_distributer, g_rank, n_gpus, cache_size, sim_b, distributed=True,
                      rank=SSD_Controllers.cudaDevice % max(int(n_gpus), 1) if rank is None else rank, num_rows=num_rows,
-                     profile=profile, sync=sync, max_batch=max_batch, cold_partitioned=cold_partitioned)
+                     profile=profile, sync=sync, max_batch=max_batch, cold_partitioned=cold_partitioned, tag64=tag64)
         self._exchange = None
 
     def attach_exchange(self, exchange):

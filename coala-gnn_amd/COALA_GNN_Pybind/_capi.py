@@ -9,8 +9,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("COALA_HIP_LIB", os.path.join(os.path.dirname(_HERE), "lib", "libcoala_hip.so"))
 
 OK, EINVAL, EHIP, ENOMEM, EIO, EFORMAT, ERANGE, ECOMM = 0, -1, -2, -3, -4, -5, -6, -7
-FLAG_SYNC, FLAG_DISTRIBUTED, FLAG_PROFILE, FLAG_COLD_PARTITIONED = 1, 2, 4, 8
+FLAG_SYNC, FLAG_DISTRIBUTED, FLAG_PROFILE, FLAG_COLD_PARTITIONED, FLAG_TAG64 = 1, 2, 4, 8, 16
 WAYS = 32
+COUNTS_RING = 8   # COALA_COUNTS_RING: count exchanges issued ahead that a communicator keeps (include/coala_hip.h)
 
 
 class CacheConfig(C.Structure):
@@ -23,7 +24,7 @@ class CacheConfig(C.Structure):
 
 class CacheGeometry(C.Structure):
     _fields_ = [("num_sets", C.c_uint64), ("num_ways", C.c_uint32), ("cache_dim", C.c_uint32), ("line_bytes", C.c_uint64),
-                ("table_bytes", C.c_uint64)]
+                ("table_bytes", C.c_uint64), ("tag_set_bytes", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class CacheProfile(C.Structure):
@@ -111,6 +112,7 @@ SYMBOLS = {
     "coala_shm_close": (_I, [_VP, _I]),
     "coala_pinned_alloc": (_I, [_U64, _I, C.POINTER(_VP), C.POINTER(_VP)]),
     "coala_pinned_free": (_I, [_VP]),
+    "coala_device_pci_bus_id": (_I, [_I, C.c_char_p, _SZ]),
     "coala_npy_parse": (_I, [C.c_char_p, _SZ, _I, C.POINTER(_I64), C.POINTER(_I), C.POINTER(_SZ), C.c_char_p, _SZ]),
     "coala_distributor_create_plain": (_I, [_VP, _I, C.POINTER(_VP)]),
     "coala_distributor_create": (_I, [_VP, _I, _I, _I, _I, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(_VP)]),

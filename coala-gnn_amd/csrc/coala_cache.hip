@@ -30,6 +30,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -44,7 +45,7 @@ constexpr uint32_t kLinkBad = 0x7FFFFFFFu;             // miss_link: id outside 
 constexpr int kStatBlocks = 2048;                      // upper bound of K2's grid
 
 struct CacheDev {
-    uint64_t* keys;        // [sets*32]
+    void* keys;            // [sets*32] tags: uint32_t when every id fits 32 bits (tag32: a set is ONE 128-B line), else uint64_t (256 B)
     uint64_t* set_cnt;     // [sets] : (gen << 32) | round-robin cursor.  gen == the current batch's generation: the cursor already
                            //          includes this batch's misses (K2 advanced it), otherwise it is the value before the batch
     uint32_t* color_meta;  // [sets*32]
@@ -61,6 +62,7 @@ struct CacheDev {
     int32_t sshift;        // log2(num_sets) if power of two else -1
     uint32_t distributed;
     uint32_t cold_partitioned; // cold row of id = id / n_gpus
+    uint32_t tag32;            // 1: 32-bit tags (num_rows <= 2^32-1, empty = 0xFFFFFFFF); 0: 64-bit tags as in the reference
     // per-batch scratch, indexed by the row's POSITION in the batch (no compaction, no list counter)
     uint64_t* set_head;    // [sets] : (gen << 32) | (position + 1) of the most recently pushed miss of this set
     uint32_t* miss_link;   // [cap] K1's verdict for every position of the batch, rewritten by every probe (nothing to clear):
@@ -123,6 +125,28 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int src_lane) {
 // native clang vectors (not HIP's float4 struct) so the in-flight rows stay in VGPRs
 typedef float vfloat4 __attribute__((ext_vector_type(4)));
 typedef unsigned long long vu64x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int vu32x4 __attribute__((ext_vector_type(4)));
+
+// How a wave reads tag sets: every lane loads 16 B.  The reference keeps 64-bit tags (isolated_cache.h:552: a set is 32 x 8 B = two
+// 128-B lines, 16 lanes x 2 tags per set, 4 sets per wave-wide load).  No dataset the reference runs has 2^32 nodes, so whenever
+// num_rows < 2^32 the table holds 32-bit tags instead: a set is ONE 128-B line (8 lanes x 4 tags, 8 sets per wave-wide load) -- half the
+// probe bytes and half the random HBM lines per probed row.  coala_cache_dump widens them again, so the table state stays comparable
+// with the oracle's bit for bit.
+template <typename TAG> struct TagGeo;
+template <> struct TagGeo<uint64_t> {
+    using vec = vu64x2;
+    static constexpr int KPL = 2;   // tags per lane
+    static constexpr int LPS = 16;  // lanes per set
+    static constexpr int SPL = 4;   // sets per wave-wide load
+    static constexpr uint64_t EMPTY = 0xFFFFFFFFFFFFFFFFull;
+};
+template <> struct TagGeo<uint32_t> {
+    using vec = vu32x4;
+    static constexpr int KPL = 4;
+    static constexpr int LPS = 8;
+    static constexpr int SPL = 8;
+    static constexpr uint32_t EMPTY = 0xFFFFFFFFu;
+};
 template <int VEC> struct VecT;
 template <> struct VecT<4> { using type = vfloat4; };
 template <> struct VecT<1> { using type = float; };
@@ -150,6 +174,10 @@ struct Geo {
 #ifndef K1_MIN_WAVES
 #define K1_MIN_WAVES 4 // waves per SIMD the register allocator must leave room for
 #endif
+// Row(-pair)s a wave keeps in flight with 32-bit tags, by line size (the 64-bit layout keeps 4: its probe state is twice as wide).
+// Bytes in flight per wave = NP x rows per pass x line: 16 KiB for 4-KiB lines; short lines get more passes so that a wave that
+// runs ONE chunk (the usual case: the grid is one chunk per wave up to 131 k rows) still has several KiB outstanding.
+constexpr int k1_np32(int cd) { return cd >= 512 ? 4 : 8; }
 constexpr int kK1Waves = 2; // waves per block (measured: 2048 x 128 threads beats 1024 x 256 and 256 x 1024 by 3-20 %)
 #ifdef COALA_DEV_KNOBS          // development builds only (build.py --dev -> libcoala_hip_dev.so): launch geometry from the environment
 constexpr int kK1MaxWaves = 4;
@@ -178,7 +206,7 @@ template <typename V> __device__ __forceinline__ void k1_store(V v, V* p) {
 #endif
 }
 
-template <int CD, int VEC, int NP = 4, bool FULL = false, int NOMISS = 0 /* development only: 1 = no miss bookkeeping */, bool REDIR = false>
+template <int CD, int VEC, typename TAG, int NP = 4, bool FULL = false, int NOMISS = 0 /* development only: 1 = no miss bookkeeping */, bool REDIR = false>
 __global__ __launch_bounds__(64 * kK1MaxWaves, K1_MIN_WAVES) void probe_gather_kernel(const int64_t* __restrict__ idx, float* __restrict__ out,
                                                                     int64_t n, uint32_t gen, uint32_t n_blocks, CacheDev c, Redirect rd) {
     // Argument order and the explicit block count are deliberate: with kernarg preloading (build.py: -mllvm -amdgpu-kernarg-preload-count=16)
@@ -189,8 +217,11 @@ __global__ __launch_bounds__(64 * kK1MaxWaves, K1_MIN_WAVES) void probe_gather_k
     //        destination row travels with the id through the software pipeline, so no load sits in front of the stores
     using G = Geo<CD, VEC, NP>;
     using V = typename VecT<VEC>::type;
+    using TG = TagGeo<TAG>;
+    using TV = typename TG::vec;
     constexpr int R = G::R;
-    constexpr int TSTEPS = (R + 3) / 4; // tag loads: four sets per wave-wide 16-B load (16 lanes x 2 keys per set)
+    static_assert(R <= 32, "per-chunk row masks are 32 bits wide");
+    constexpr int TSTEPS = (R + TG::SPL - 1) / TG::SPL; // tag loads per chunk: SPL sets per wave-wide 16-B load (LPS lanes x KPL tags per set)
     const int lane = threadIdx.x & 63;
 #ifdef COALA_DEV_KNOBS
     const int wpb = (int)(blockDim.x >> 6);
@@ -201,21 +232,22 @@ __global__ __launch_bounds__(64 * kK1MaxWaves, K1_MIN_WAVES) void probe_gather_k
     const int64_t n_waves = (int64_t)n_blocks * wpb;
     const int64_t n_chunks = (n + R - 1) / R;
     const uint32_t nunits = c.dim / VEC; // accesses per output row
+    const TAG* __restrict__ keys = reinterpret_cast<const TAG*>(c.keys);
 
-    // probe state of one chunk: lane l looks at row q = 4t + l/16, keys 2(l%16), 2(l%16)+1 of that row's set
-    struct Ids { uint64_t id[TSTEPS]; bool valid[TSTEPS]; int64_t drow[REDIR ? TSTEPS : 1]; };
-    struct Tags { uint64_t id[TSTEPS]; uint64_t set[TSTEPS]; vu64x2 kk[TSTEPS]; bool ok[TSTEPS]; bool valid[TSTEPS]; int64_t drow[REDIR ? TSTEPS : 1]; };
+    // probe state of one chunk: lane l looks at row q = SPL*t + l/LPS, tags KPL*(l%LPS) .. KPL*(l%LPS)+KPL-1 of that row's set
+    struct Ids { uint64_t id[TSTEPS]; bool valid[TSTEPS]; int32_t drow[REDIR ? TSTEPS : 1]; };
+    struct Tags { uint64_t id[TSTEPS]; uint32_t set[TSTEPS]; TV kk[TSTEPS]; bool ok[TSTEPS]; bool valid[TSTEPS]; int32_t drow[REDIR ? TSTEPS : 1]; };
     auto load_ids = [&](int64_t chunk) {
         Ids r;
 #pragma unroll
         for (int t = 0; t < TSTEPS; ++t) {
-            const int q_l = t * 4 + (lane >> 4);
+            const int q_l = t * TG::SPL + lane / TG::LPS;
             const int64_t i_l = chunk * R + q_l;
             r.valid[t] = (chunk < n_chunks) && (q_l < R) && (i_l < n);
             r.id[t] = r.valid[t] ? (uint64_t)idx[i_l] : 0;
-            if (REDIR) { // destination row: >= 0 row of the batch's own output, < 0 encodes row -(v+1) of rd.out
-                int64_t d = i_l;
-                if (r.valid[t] && i_l >= rd.begin && i_l < rd.end) d = -((rd.row_map ? rd.row_map[i_l - rd.begin] : i_l - rd.begin) + 1);
+            if (REDIR) { // destination: -1 = row i_l of the batch's own output, v >= 0 = row v of rd.out (a batch has < 2^31 rows)
+                int32_t d = -1;
+                if (r.valid[t] && i_l >= rd.begin && i_l < rd.end) d = (int32_t)(rd.row_map ? rd.row_map[i_l - rd.begin] : i_l - rd.begin);
                 r.drow[t] = d;
             }
         }
@@ -229,9 +261,9 @@ __global__ __launch_bounds__(64 * kK1MaxWaves, K1_MIN_WAVES) void probe_gather_k
             r.valid[t] = ids.valid[t];
             if (REDIR) r.drow[t] = ids.drow[t];
             r.ok[t] = ids.valid[t] && ids.id[t] < c.num_rows;
-            r.set[t] = r.ok[t] ? set_of(c, ids.id[t]) : 0;
-            r.kk[t] = vu64x2{kEmptyKey, kEmptyKey};
-            if (r.ok[t]) r.kk[t] = *reinterpret_cast<const vu64x2*>(c.keys + r.set[t] * COALA_WAYS + (lane & 15) * 2);
+            r.set[t] = r.ok[t] ? (uint32_t)set_of(c, ids.id[t]) : 0u;
+            r.kk[t] = TV(TG::EMPTY);
+            if (r.ok[t]) r.kk[t] = *reinterpret_cast<const TV*>(keys + (uint64_t)r.set[t] * COALA_WAYS + (lane % TG::LPS) * TG::KPL);
         }
         return r;
     };
@@ -244,39 +276,49 @@ __global__ __launch_bounds__(64 * kK1MaxWaves, K1_MIN_WAVES) void probe_gather_k
     for (; chunk < n_chunks; chunk += n_waves) {
         const int64_t base = chunk * R;
         uint32_t slot[R];       // wave-uniform: set*32 + way for hits
-        int64_t drow[REDIR ? R : 1]; // wave-uniform: destination row (REDIR only)
+        int32_t drow[REDIR ? R : 1]; // wave-uniform: destination row in rd.out, -1 = not redirected (REDIR only)
         uint32_t hitmask = 0;   // bit q: row q hits
         uint32_t missmask = 0;  // bit q: row q misses (valid, in range, no tag match)
         uint32_t badmask = 0;   // bit q: id outside [0, num_rows)
-        uint64_t my_set = 0;    // lane q < R: set of row q
+        uint32_t my_set = 0;    // lane q < R: set of row q
 #pragma unroll
         for (int t = 0; t < TSTEPS; ++t) {
-            const uint64_t m0 = __ballot(tags.ok[t] && tags.kk[t].x == tags.id[t]); // even ways
-            const uint64_t m1 = __ballot(tags.ok[t] && tags.kk[t].y == tags.id[t]); // odd ways
+            uint64_t m[TG::KPL];
+#pragma unroll
+            for (int k = 0; k < TG::KPL; ++k) m[k] = __ballot(tags.ok[t] && tags.kk[t][k] == (TAG)tags.id[t]); // tag position k of every lane
             const uint64_t okm = __ballot(tags.ok[t]);
             const uint64_t vm = __ballot(tags.valid[t]);
 #pragma unroll
-            for (int qq = 0; qq < 4; ++qq) {
-                const int q = t * 4 + qq;
+            for (int qq = 0; qq < TG::SPL; ++qq) {
+                const int q = t * TG::SPL + qq;
                 if (q < R) {
-                    const uint32_t a = (uint32_t)(m0 >> (16 * qq)) & 0xFFFFu;
-                    const uint32_t b = (uint32_t)(m1 >> (16 * qq)) & 0xFFFFu;
-                    const uint32_t mm = a | b;
-                    const bool row_valid = (vm >> (16 * qq)) & 1;
-                    const bool row_ok = (okm >> (16 * qq)) & 1;
-                    const uint64_t set_q = readlane64(tags.set[t], 16 * qq);
+                    constexpr uint32_t FM = (1u << TG::LPS) - 1u;
+                    uint32_t f[TG::KPL];
+                    uint32_t mm = 0;
+#pragma unroll
+                    for (int k = 0; k < TG::KPL; ++k) {
+                        f[k] = (uint32_t)(m[k] >> (TG::LPS * qq)) & FM;
+                        mm |= f[k];
+                    }
+                    const bool row_valid = (vm >> (TG::LPS * qq)) & 1;
+                    const bool row_ok = (okm >> (TG::LPS * qq)) & 1;
+                    const uint32_t set_q = (uint32_t)__builtin_amdgcn_readlane((int)tags.set[t], TG::LPS * qq);
                     uint32_t way = 0;
-                    if (mm) { // lowest matching way wins (isolated_cache.h:165-172)
+                    if (mm) { // lowest matching way wins (isolated_cache.h:165-172): way = KPL * lane-in-set + tag position
                         const int j = __builtin_ctz(mm);
-                        way = 2 * j + (((a >> j) & 1) ? 0 : 1);
+                        uint32_t kbest = TG::KPL - 1;
+#pragma unroll
+                        for (int k = TG::KPL - 2; k >= 0; --k)
+                            if ((f[k] >> j) & 1) kbest = (uint32_t)k;
+                        way = (uint32_t)(TG::KPL * j) + kbest;
                         hitmask |= 1u << q;
                     } else if (row_ok) {
                         missmask |= 1u << q;
                     } else if (row_valid) {
                         badmask |= 1u << q;
                     }
-                    slot[q] = (uint32_t)(set_q * COALA_WAYS) + way;
-                    if (REDIR) drow[q] = (int64_t)readlane64((uint64_t)tags.drow[t], 16 * qq);
+                    slot[q] = set_q * COALA_WAYS + way;
+                    if (REDIR) drow[q] = __builtin_amdgcn_readlane(tags.drow[t], TG::LPS * qq);
                     if (lane == q) my_set = set_q;
                 }
             }
@@ -319,8 +361,8 @@ __global__ __launch_bounds__(64 * kK1MaxWaves, K1_MIN_WAVES) void probe_gather_k
             const bool bad = (badmask >> q) & 1;
             V* dst = reinterpret_cast<V*>(out + (base + q) * (int64_t)c.dim);
             if (REDIR) {
-                const int64_t dr = (G::RPP == 2) ? (sub ? drow[p * G::RPP + (G::RPP - 1)] : drow[p * G::RPP]) : drow[p];
-                if (dr < 0) dst = reinterpret_cast<V*>(rd.out + (-(dr + 1)) * (int64_t)c.dim);
+                const int32_t dr = (G::RPP == 2) ? (sub ? drow[p * G::RPP + (G::RPP - 1)] : drow[p * G::RPP]) : drow[p];
+                if (dr >= 0) dst = reinterpret_cast<V*>(rd.out + (int64_t)dr * (int64_t)c.dim);
             }
 #pragma unroll
             for (int v = 0; v < G::VPL; ++v) {
@@ -361,7 +403,7 @@ __global__ __launch_bounds__(256, K1_MIN_WAVES) void k1_stage_kernel(const int64
     const bool ok = i_l < n && id < c.num_rows;
     const uint64_t set = ok ? set_of(c, id) : 0;
     vu64x2 kk = vu64x2{kEmptyKey, kEmptyKey};
-    if (ok) kk = *reinterpret_cast<const vu64x2*>(c.keys + set * COALA_WAYS + (lane & 15) * 2);
+    if (ok) kk = *reinterpret_cast<const vu64x2*>(reinterpret_cast<const uint64_t*>(c.keys) + set * COALA_WAYS + (lane & 15) * 2); // 64-bit tag layout only (COALA_FLAG_TAG64)
     const uint64_t m0 = __ballot(ok && kk.x == id), m1 = __ballot(ok && kk.y == id);
     if (STAGE == 2) {
         if ((m0 ^ m1) == 0x123456789ABCDEFull) out[0] = 1.f;
@@ -426,116 +468,156 @@ __global__ __launch_bounds__(256) void miss_fill_kernel(CacheDev c, const int64_
           st_pack |= v << (8 * u);
       }
       if (!__ballot(st_pack != 0)) continue; // nothing but hits in these U tiles
+      // ---- per-lane state of ONE missed row (the lane "holds" it): rank inside its set, way, winner flag
+      uint32_t slot_l = 0, win_l = 0;
+      uint64_t id_l = 0;
+      int64_t drow_l = 0;                    // destination row; < 0 encodes row -(v+1) of rd.out
+      auto rank_at = [&](uint32_t pos) {
+          id_l = (uint64_t)idx[pos];
+          drow_l = (int64_t)pos;
+          if (REDIR && (int64_t)pos >= rd.begin && (int64_t)pos < rd.end)
+              drow_l = -((rd.row_map ? rd.row_map[(int64_t)pos - rd.begin] : (int64_t)pos - rd.begin) + 1);
+          const uint64_t set = set_of(c, id_l);
+          uint32_t cur = (uint32_t)c.set_head[set]; // tagged with this generation: this row was pushed on it by K1
+          uint32_t total = 0, rank = 0;
+          while (cur) {
+              const uint32_t p2 = cur - 1;
+              ++total;
+              rank += (p2 < pos) ? 1u : 0u;
+              cur = c.miss_link[p2] & ~kLinkMiss;
+          }
+          // the cursor before this batch: the set's first-ranked miss advances it below, tagged with the generation
+          const uint64_t cv = __hip_atomic_load(c.set_cnt + set, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const uint32_t cnt0 = ((uint32_t)(cv >> 32) == gen) ? (uint32_t)cv - total : (uint32_t)cv;
+          if (rank == 0) __hip_atomic_store(c.set_cnt + set, ((uint64_t)gen << 32) | (uint32_t)(cnt0 + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const uint32_t way = (cnt0 + rank) & (COALA_WAYS - 1);              // isolated_cache.h:203
+          slot_l = (uint32_t)(set * COALA_WAYS) + way;
+          win_l = (rank + COALA_WAYS >= total) ? 1u : 0u;                     // nobody later in the batch lands here
+          if (win_l) {
+              if (c.tag32) reinterpret_cast<uint32_t*>(c.keys)[slot_l] = (uint32_t)id_l;   // isolated_cache.h:434 (a uniform branch)
+              else reinterpret_cast<uint64_t*>(c.keys)[slot_l] = id_l;
+              if (c.color_counters) {
+                  // the pre-batch occupant leaves (:427-429), the winner enters (:437-441); rows that were inserted
+                  // and overwritten again inside this batch cancel out
+                  const int32_t col = c.node_color[id_l];
+                  atomicSub(c.color_counters + c.color_meta[slot_l], 1);
+                  atomicAdd(c.color_counters + col, 1);
+                  c.color_meta[slot_l] = (uint32_t)col;
+              }
+          }
+      };
+      // ---- stream up to R missed rows: pass p of this lane's half-wave moves the row held by lane srcl[p]
+      auto move_group = [&](const int (&srcl)[G::PASSES], const bool (&live)[G::PASSES]) {
+          V val[G::PASSES][G::VPL];
+          uint32_t slot_[G::PASSES];
+          uint64_t id[G::PASSES];
+          int64_t drow[G::PASSES];
+          bool winner[G::PASSES];
+#pragma unroll
+          for (int p = 0; p < G::PASSES; ++p) {
+              slot_[p] = (uint32_t)__shfl((int)slot_l, srcl[p]);
+              winner[p] = __shfl((int)win_l, srcl[p]) != 0;
+              id[p] = shfl64(id_l, srcl[p]);
+              drow[p] = (int64_t)shfl64((uint64_t)drow_l, srcl[p]);
+          }
+#pragma unroll
+          for (int p = 0; p < G::PASSES; ++p) {
+              const V* src = reinterpret_cast<const V*>(c.cold + cold_row_of(c, id[p]) * (uint64_t)c.dim); // cold stride = dim
+#pragma unroll
+              for (int v = 0; v < G::VPL; ++v) {
+                  const uint32_t u = v * G::LPR + l_in;
+                  if (live[p] && u < nunits) val[p][v] = nt_load(src + u);
+              }
+          }
+#pragma unroll
+          for (int p = 0; p < G::PASSES; ++p) {
+              V* dst = (REDIR && drow[p] < 0) ? reinterpret_cast<V*>(rd.out + (uint64_t)(-(drow[p] + 1)) * c.dim)
+                                              : reinterpret_cast<V*>(out + (uint64_t)drow[p] * c.dim);
+              V* line = reinterpret_cast<V*>(c.lines + (uint64_t)slot_[p] * CD);
+#pragma unroll
+              for (int v = 0; v < G::VPL; ++v) {
+                  const uint32_t u = v * G::LPR + l_in;
+                  if (live[p] && u < nunits) {
+                      nt_store(val[p][v], dst + u);
+                      if (winner[p]) nt_store(val[p][v], line + u);
+                  }
+              }
+          }
+      };
+      // the rows held by the lanes of `holders` (each already ranked), streamed R at a time, compacted
+      auto stream_holders = [&](uint64_t holders) {
+          int srcl[G::PASSES];
+          bool live[G::PASSES];
+          while (holders) {
+#pragma unroll
+              for (int p = 0; p < G::PASSES; ++p) {
+                  int l0 = -1, l1 = -1;
+                  if (holders) { l0 = __builtin_ctzll(holders); holders &= holders - 1; }
+                  if (G::RPP == 2 && holders) { l1 = __builtin_ctzll(holders); holders &= holders - 1; }
+                  const int l = (G::RPP == 2 && sub) ? l1 : l0;
+                  live[p] = l >= 0;
+                  srcl[p] = l >= 0 ? l : 0;
+              }
+              move_group(srcl, live);
+          }
+      };
+      // verdicts of the U tiles as wave-uniform masks
+      uint64_t mmask[U];
+      uint32_t total_miss = 0, worst = 0;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+          const uint8_t st = (uint8_t)(st_pack >> (8 * u));
+          mmask[u] = __ballot(st == 1);
+          my_miss += (st == 1);
+          my_bad += (st == 2);
+          const uint32_t cnt = (uint32_t)__builtin_popcountll(mmask[u]);
+          total_miss += cnt;
+          worst = cnt > worst ? cnt : worst;
+      }
+      if (!total_miss) continue;
+      if (total_miss <= 64 && (int)worst <= sparse_max) {
+          // Few misses in ALL U tiles (the multi-GPU steady state: the caches of 8 GPUs hold most of the table).  Tile by tile a wave
+          // would pay the whole dependency chain -- verdict -> id -> chain walk -> cursor -> PCIe read -> store, ~8 us -- once per
+          // tile with one or two rows in flight (2 % misses: 56 us for 2.3 MB, latency- not link-bound).  Instead lane j takes the
+          // j-th miss of the U tiles, all are ranked at once, and the rows stream R at a time.
+          uint32_t k = (uint32_t)lane;
+          int u_sel = -1;
+          uint64_t m_sel = 0;
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+              const uint32_t cnt = (uint32_t)__builtin_popcountll(mmask[u]);
+              if (u_sel < 0) {
+                  if (k < cnt) { u_sel = u; m_sel = mmask[u]; }
+                  else k -= cnt;
+              }
+          }
+          if (u_sel >= 0) {
+              for (uint32_t i = 0; i < k; ++i) m_sel &= m_sel - 1;   // the k-th miss of that tile sits in lane ctz(m_sel)
+              const uint32_t pos = pos_of(rs, (uint32_t)((tile0 + u_sel * n_waves) * tile_rows + __builtin_ctzll(m_sel)));
+              rank_at(pos);
+          }
+          stream_holders(total_miss >= 64 ? ~0ull : ((1ull << total_miss) - 1ull));
+          continue;
+      }
 #pragma nounroll
       for (int u = 0; u < U; ++u) {
         const uint8_t st = (uint8_t)(st_pack >> (8 * u));
-        const uint64_t tile_mask = __ballot(st == 1);
-        if (!__ballot(st != 0)) continue;
+        const uint64_t tile_mask = __ballot(st == 1);   // (recomputed: mmask[] must not be indexed by a run-time u)
+        if (!tile_mask) continue;
         // a lane with a verdict has a valid position (recomputed: cheaper than keeping U of them alive across the loop)
         const uint32_t pos_l = st ? pos_of(rs, (uint32_t)((tile0 + u * n_waves) * tile_rows + lane)) : 0u;
-        my_miss += (st == 1);
-        my_bad += (st == 2);
-        if (!tile_mask) continue;
-        // ---- a lane holding a miss ranks it inside its set and picks the way
-        uint32_t slot_l = 0, win_l = 0;
-        uint64_t id_l = 0;
-        int64_t drow_l = (int64_t)pos_l;       // destination row; < 0 encodes row -(v+1) of rd.out
-        auto rank_mine = [&]() {
-            id_l = (uint64_t)idx[pos_l];
-            if (REDIR && (int64_t)pos_l >= rd.begin && (int64_t)pos_l < rd.end)
-                drow_l = -((rd.row_map ? rd.row_map[(int64_t)pos_l - rd.begin] : (int64_t)pos_l - rd.begin) + 1);
-            const uint64_t set = set_of(c, id_l);
-            uint32_t cur = (uint32_t)c.set_head[set]; // tagged with this generation: this row was pushed on it by K1
-            uint32_t total = 0, rank = 0;
-            while (cur) {
-                const uint32_t p2 = cur - 1;
-                ++total;
-                rank += (p2 < pos_l) ? 1u : 0u;
-                cur = c.miss_link[p2] & ~kLinkMiss;
-            }
-            // the cursor before this batch: the set's first-ranked miss advances it below, tagged with the generation
-            const uint64_t cv = __hip_atomic_load(c.set_cnt + set, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t cnt0 = ((uint32_t)(cv >> 32) == gen) ? (uint32_t)cv - total : (uint32_t)cv;
-            if (rank == 0) __hip_atomic_store(c.set_cnt + set, ((uint64_t)gen << 32) | (uint32_t)(cnt0 + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t way = (cnt0 + rank) & (COALA_WAYS - 1);              // isolated_cache.h:203
-            slot_l = (uint32_t)(set * COALA_WAYS) + way;
-            win_l = (rank + COALA_WAYS >= total) ? 1u : 0u;                     // nobody later in the batch lands here
-            if (win_l) {
-                c.keys[slot_l] = id_l;                                          // isolated_cache.h:434
-                if (c.color_counters) {
-                    // the pre-batch occupant leaves (:427-429), the winner enters (:437-441); rows that were inserted
-                    // and overwritten again inside this batch cancel out
-                    const int32_t col = c.node_color[id_l];
-                    atomicSub(c.color_counters + c.color_meta[slot_l], 1);
-                    atomicAdd(c.color_counters + col, 1);
-                    c.color_meta[slot_l] = (uint32_t)col;
-                }
-            }
-        };
-        // ---- stream up to R missed rows: pass p of this lane's half-wave moves the row held by lane srcl[p]
-        auto move_group = [&](const int (&srcl)[G::PASSES], const bool (&live)[G::PASSES]) {
-            V val[G::PASSES][G::VPL];
-            uint32_t slot_[G::PASSES];
-            uint64_t id[G::PASSES];
-            int64_t drow[G::PASSES];
-            bool winner[G::PASSES];
-#pragma unroll
-            for (int p = 0; p < G::PASSES; ++p) {
-                slot_[p] = (uint32_t)__shfl((int)slot_l, srcl[p]);
-                winner[p] = __shfl((int)win_l, srcl[p]) != 0;
-                id[p] = shfl64(id_l, srcl[p]);
-                drow[p] = (int64_t)shfl64((uint64_t)drow_l, srcl[p]);
-            }
-#pragma unroll
-            for (int p = 0; p < G::PASSES; ++p) {
-                const V* src = reinterpret_cast<const V*>(c.cold + cold_row_of(c, id[p]) * (uint64_t)c.dim); // cold stride = dim
-#pragma unroll
-                for (int v = 0; v < G::VPL; ++v) {
-                    const uint32_t u = v * G::LPR + l_in;
-                    if (live[p] && u < nunits) val[p][v] = nt_load(src + u);
-                }
-            }
-#pragma unroll
-            for (int p = 0; p < G::PASSES; ++p) {
-                V* dst = (REDIR && drow[p] < 0) ? reinterpret_cast<V*>(rd.out + (uint64_t)(-(drow[p] + 1)) * c.dim)
-                                                : reinterpret_cast<V*>(out + (uint64_t)drow[p] * c.dim);
-                V* line = reinterpret_cast<V*>(c.lines + (uint64_t)slot_[p] * CD);
-#pragma unroll
-                for (int v = 0; v < G::VPL; ++v) {
-                    const uint32_t u = v * G::LPR + l_in;
-                    if (live[p] && u < nunits) {
-                        nt_store(val[p][v], dst + u);
-                        if (winner[p]) nt_store(val[p][v], line + u);
-                    }
-                }
-            }
-        };
-        int srcl[G::PASSES];
-        bool live[G::PASSES];
         if (__builtin_popcountll(tile_mask) <= sparse_max) {
-            // Few misses in this tile (the multi-GPU steady state): walking it chunk by chunk would stream one row at a time and
-            // leave the PCIe pipe half empty (16 % misses: 49 GB/s, 4 %: 39 GB/s).  Rank every missed row of the tile at once,
-            // then stream them R at a time, compacted.
-            if (st == 1) rank_mine();
-            uint64_t m = tile_mask;
-            while (m) {
-#pragma unroll
-                for (int p = 0; p < G::PASSES; ++p) {
-                    int l0 = -1, l1 = -1;
-                    if (m) { l0 = __builtin_ctzll(m); m &= m - 1; }
-                    if (G::RPP == 2 && m) { l1 = __builtin_ctzll(m); m &= m - 1; }
-                    const int l = (G::RPP == 2 && sub) ? l1 : l0;
-                    live[p] = l >= 0;
-                    srcl[p] = l >= 0 ? l : 0;
-                }
-                move_group(srcl, live);
-            }
+            // Few misses in this tile: rank every missed row of the tile at once, then stream them R at a time, compacted.
+            if (st == 1) rank_at(pos_l);
+            stream_holders(tile_mask);
         } else {
+            int srcl[G::PASSES];
+            bool live[G::PASSES];
             for (int ck = 0; ck < chunks_per_tile; ++ck) {
                 const uint32_t live_mask = (uint32_t)(tile_mask >> (ck * R)) & ((1u << R) - 1u);
                 if (!live_mask) continue;
                 const int lane0 = ck * R;              // lanes lane0 .. lane0+R-1 hold this chunk's rows
-                if (st == 1 && lane >= lane0 && lane < lane0 + R) rank_mine();
+                if (st == 1 && lane >= lane0 && lane < lane0 + R) rank_at(pos_l);
 #pragma unroll
                 for (int p = 0; p < G::PASSES; ++p) {
                     const int q = p * G::RPP + sub;
@@ -742,7 +824,7 @@ struct coala_cache {
     Redirect open_redirect{0, 0, nullptr, nullptr};       // the open batch's redirect (set by the probe, reused by its fills)
     int k2_tile_rows = 0;                 // rows per verdict tile of K2: 64 for a host cold tier, 0 = one chunk (COALA_K2_TILE_ROWS)
     int k2_sparse_max = 0;                // tiles with at most this many misses are streamed compacted (host tier; 0 = never)
-    int k1_passes = 4;                    // rows(-pairs) in flight per wave in K1 (tunable: COALA_K1_PASSES = 2 | 4)
+    int k1_passes = 0;                    // development builds: rows(-pairs) in flight per wave in K1 (COALA_K1_PASSES = 2 | 4 | 8 | 16); 0 = the product's choice per line size
     int k1_grid_cap = 16384;              // K1 blocks: one chunk per wave up to 131,072 rows.  Measured (tools/k1_insitu.py, tools/k1_bench): 28.5 k rows at 32 %
                                           // hits in situ: 2048 blocks -> 22.3 us, 4096 -> 20.7, 8192 -> 20.6; all-hit 36,864 rows: 53.8 / 53.1 / 51.4 us;
                                           // all-hit 123,904 rows: 192.5 / 192.3 / 190.1 / 185.3 us at 2048 / 4096 / 8192 / 16384; 1.08 M x 512 B: 232 -> 227 us
@@ -927,6 +1009,12 @@ int coala_cache_create(const coala_cache_config_t* cfg, coala_cache_t** out) {
     d.distributed = (cfg->flags & COALA_FLAG_DISTRIBUTED) ? 1u : 0u;
     d.cold_partitioned = (cfg->flags & COALA_FLAG_COLD_PARTITIONED) ? 1u : 0u;
     d.cold = cfg->cold_table;
+    // 32-bit tags whenever every id fits (0xFFFFFFFF is the empty tag): a set is then one 128-B line instead of two
+    d.tag32 = (!(cfg->flags & COALA_FLAG_TAG64) && cfg->num_rows <= 0xFFFFFFFFull) ? 1u : 0u;
+#ifdef COALA_DEV_KNOBS
+    if (const char* e = getenv("COALA_K1_TAG64")) if (atoi(e) == 1) d.tag32 = 0u;
+#endif
+    const uint64_t tag_bytes = d.tag32 ? 4 : 8;
     int rc = COALA_OK;
     auto alloc = [&](void** p, uint64_t bytes) -> int {
         hipError_t e = hipMalloc(p, bytes);
@@ -935,14 +1023,14 @@ int coala_cache_create(const coala_cache_config_t* cfg, coala_cache_t** out) {
         return COALA_OK;
     };
     do {
-        if ((rc = alloc((void**)&d.keys, slots * 8))) break;
+        if ((rc = alloc((void**)&d.keys, slots * tag_bytes))) break;
         if ((rc = alloc((void**)&d.set_cnt, sets * 8))) break;
         if ((rc = alloc((void**)&d.color_meta, slots * 4))) break;
         if ((rc = alloc((void**)&d.set_head, sets * 8))) break;
         if ((rc = alloc((void**)&d.stats, kStatBlocks * 2 * 8))) break;
         if ((rc = alloc((void**)&d.lines, slots * (uint64_t)cd * 4))) break;
         if ((rc = alloc((void**)&h->route_bases, 65 * 8))) break;
-        if (hipMemset(d.keys, 0xFF, slots * 8) != hipSuccess || hipMemset(d.set_cnt, 0, sets * 8) != hipSuccess ||
+        if (hipMemset(d.keys, 0xFF, slots * tag_bytes) != hipSuccess || hipMemset(d.set_cnt, 0, sets * 8) != hipSuccess ||
             hipMemset(d.color_meta, 0, slots * 4) != hipSuccess || hipMemset(d.set_head, 0, sets * 8) != hipSuccess ||
             hipMemset(d.stats, 0, kStatBlocks * 2 * 8) != hipSuccess) {
             rc = fail(COALA_EHIP, "hipMemset failed");
@@ -970,7 +1058,7 @@ int coala_cache_create(const coala_cache_config_t* cfg, coala_cache_t** out) {
         }
         h->gen = 0;
 #ifdef COALA_DEV_KNOBS
-        if (const char* e = getenv("COALA_K1_PASSES")) h->k1_passes = atoi(e) == 2 ? 2 : 4;
+        if (const char* e = getenv("COALA_K1_PASSES")) { int v = atoi(e); if (v == 2 || v == 4 || v == 8 || v == 16) h->k1_passes = v; }
         if (const char* e = getenv("COALA_K1_GRID")) { int g = atoi(e); if (g >= 1 && g <= 65535) h->k1_grid_cap = g; }
         if (const char* e = getenv("COALA_K1_WAVES")) { int w = atoi(e); if (w == 1 || w == 2 || w == 4) h->k1_waves = w; }
 #endif
@@ -1034,6 +1122,8 @@ int coala_cache_geometry(const coala_cache_t* h, coala_cache_geometry_t* out) {
     out->cache_dim = h->d.cache_dim;
     out->line_bytes = (uint64_t)h->d.cache_dim * 4;
     out->table_bytes = h->table_bytes;
+    out->tag_set_bytes = h->d.tag32 ? COALA_WAYS * 4u : COALA_WAYS * 8u;
+    out->reserved = 0;
     return COALA_OK;
 }
 
@@ -1116,24 +1206,38 @@ static int read_feature_impl(coala_cache_t* h, float* out, const int64_t* idx, i
         constexpr int CD = geo_cd(geo);
         constexpr int VEC = geo_vec(geo);
         using G = Geo<CD, VEC>;
-        const int64_t chunks = (n + G::R - 1) / G::R;
         // K1: 2-wave blocks, every wave resident; grid-stride over the chunks
         if (phases & kPhaseProbe) {
             ProfScope ps(h, s, 0, (uint64_t)n);
             const bool full = (VEC == 4) && ((int)d.dim == CD);
-            const dim3 grid(grid_for(chunks, h->k1_waves, h->k1_grid_cap)), block(64 * h->k1_waves);
-            if (redir) {
-                ps.launch(probe_gather_kernel<CD, VEC, 4, false, 0, true>, grid, block, idx, out, n, gen, (uint32_t)grid.x, d, rd);
-            } else if (h->k1_passes == 2) {
-                using G2 = Geo<CD, VEC, 2>;
-                const int64_t chunks2 = (n + G2::R - 1) / G2::R;
-                const dim3 grid2(grid_for(chunks2, h->k1_waves, h->k1_grid_cap));
-                ps.launch(probe_gather_kernel<CD, VEC, 2, false>, grid2, block, idx, out, n, gen, (uint32_t)grid2.x, d, rd);
-            } else if (full) {
-                ps.launch(probe_gather_kernel<CD, VEC, 4, true>, grid, block, idx, out, n, gen, (uint32_t)grid.x, d, rd);
-            } else {
-                ps.launch(probe_gather_kernel<CD, VEC, 4, false>, grid, block, idx, out, n, gen, (uint32_t)grid.x, d, rd);
-            }
+            auto launch_k1 = [&](auto tag_c, auto np_c) {
+                using TAG = decltype(tag_c);
+                constexpr int NP = decltype(np_c)::value;
+                // the redirecting variant carries a destination per row: with 16 rows per chunk (512-B lines, 8 passes) it spills -> 4 passes there
+                constexpr int NPR = (Geo<CD, VEC, NP>::R > 8) ? NP / 2 : NP;
+                using GK = Geo<CD, VEC, NP>;
+                using GR = Geo<CD, VEC, NPR>;
+                const int64_t chunks = redir ? (n + GR::R - 1) / GR::R : (n + GK::R - 1) / GK::R;
+                const dim3 grid(grid_for(chunks, h->k1_waves, h->k1_grid_cap)), block(64 * h->k1_waves);
+                if (redir) ps.launch(probe_gather_kernel<CD, VEC, TAG, NPR, false, 0, true>, grid, block, idx, out, n, gen, (uint32_t)grid.x, d, rd);
+                else if (full) ps.launch(probe_gather_kernel<CD, VEC, TAG, NP, true>, grid, block, idx, out, n, gen, (uint32_t)grid.x, d, rd);
+                else ps.launch(probe_gather_kernel<CD, VEC, TAG, NP, false>, grid, block, idx, out, n, gen, (uint32_t)grid.x, d, rd);
+            };
+#ifdef COALA_DEV_KNOBS
+            if (h->k1_passes) { // development builds: rows in flight per wave from the environment
+                auto by_np = [&](auto tag_c) {
+                    switch (h->k1_passes) {
+                        case 2: launch_k1(tag_c, std::integral_constant<int, 2>{}); break;
+                        case 8: launch_k1(tag_c, std::integral_constant<int, 8>{}); break;
+                        case 16: launch_k1(tag_c, std::integral_constant<int, (Geo<CD, VEC, 16>::R <= 32 ? 16 : 8)>{}); break;
+                        default: launch_k1(tag_c, std::integral_constant<int, 4>{}); break;
+                    }
+                };
+                if (d.tag32) by_np(uint32_t{}); else by_np(uint64_t{});
+            } else
+#endif
+            if (d.tag32) launch_k1(uint32_t{}, std::integral_constant<int, k1_np32(CD)>{});
+            else launch_k1(uint64_t{}, std::integral_constant<int, 4>{});
         }
         if ((phases & kPhaseFill) && fill_rows > 0) {
             // verdict tile: 64 rows behind the narrow host-tier grid, one chunk behind the wide HBM-tier grid (see the kernel)
@@ -1284,10 +1388,10 @@ int coala_dev_k1_stage(coala_cache_t* h, float* out, const int64_t* idx, int64_t
         case 2: hipLaunchKernelGGL(k1_stage_kernel<2>, grid, block, 0, s, idx, out, n, h->d); break;
         case 3: hipLaunchKernelGGL(k1_stage_kernel<3>, grid, block, 0, s, idx, out, n, h->d); break;
         case 4: // the product kernel without the miss bookkeeping (hits copied, misses ignored)
-            hipLaunchKernelGGL((probe_gather_kernel<1024, 4, 4, true, 1>), grid, block, 0, s, idx, out, n, 0xFFFFFFF0u, grid.x, h->d, Redirect{0, 0, nullptr, nullptr});
+            hipLaunchKernelGGL((probe_gather_kernel<1024, 4, uint64_t, 4, true, 1>), grid, block, 0, s, idx, out, n, 0xFFFFFFF0u, grid.x, h->d, Redirect{0, 0, nullptr, nullptr});
             break;
         default: // the product kernel itself on a generation nobody consumes
-            hipLaunchKernelGGL((probe_gather_kernel<1024, 4, 4, true, 0>), grid, block, 0, s, idx, out, n, 0xFFFFFFF1u, grid.x, h->d, Redirect{0, 0, nullptr, nullptr});
+            hipLaunchKernelGGL((probe_gather_kernel<1024, 4, uint64_t, 4, true, 0>), grid, block, 0, s, idx, out, n, 0xFFFFFFF1u, grid.x, h->d, Redirect{0, 0, nullptr, nullptr});
             break;
     }
     return COALA_OK;
@@ -1378,7 +1482,15 @@ int coala_cache_dump(coala_cache_t* h, uint64_t* keys, uint32_t* set_cnt, uint32
     if (int rc_ = follow_stream(h, (hipStream_t)stream)) return rc_;
     const uint64_t slots = h->d.num_sets * COALA_WAYS;
     HIPCHK(hipStreamSynchronize(s));
-    if (keys) HIPCHK(hipMemcpy(keys, h->d.keys, slots * 8, hipMemcpyDeviceToHost));
+    if (keys) {
+        if (h->d.tag32) { // widened to the reference's 64-bit tags (empty = all ones), in place from the back
+            uint32_t* narrow = reinterpret_cast<uint32_t*>(keys);
+            HIPCHK(hipMemcpy(narrow, h->d.keys, slots * 4, hipMemcpyDeviceToHost));
+            for (uint64_t k = slots; k-- > 0;) keys[k] = narrow[k] == 0xFFFFFFFFu ? kEmptyKey : (uint64_t)narrow[k];
+        } else {
+            HIPCHK(hipMemcpy(keys, h->d.keys, slots * 8, hipMemcpyDeviceToHost));
+        }
+    }
     if (set_cnt) HIPCHK(hipMemcpy2D(set_cnt, 4, h->d.set_cnt, 8, 4, h->d.num_sets, hipMemcpyDeviceToHost)); // the cursors without their generation tags
     if (color_meta) HIPCHK(hipMemcpy(color_meta, h->d.color_meta, slots * 4, hipMemcpyDeviceToHost));
     return COALA_OK;

@@ -54,6 +54,8 @@ struct Transport {
                              const size_t* rdis, size_t elem_bytes, bool include_self, hipStream_t st) = 0;
     // make the peers fail instead of hang after a local error between collectives; the transport is unusable afterwards
     virtual void abort() = 0;
+    // ranks as the transport itself counts them (not the number it was told at creation); negative on failure
+    virtual int size() = 0;
 };
 
 // ------------------------------------------------------------------------------------------------------------ RCCL
@@ -85,6 +87,12 @@ struct RcclTransport : Transport {
     void abort() override {
         if (comm) (void)ncclCommAbort(comm);
         comm = nullptr;
+    }
+    int size() override {
+        if (!comm) return fail(COALA_ECOMM, "the RCCL communicator was aborted");
+        int n = -1;
+        NCCLCHK(ncclCommCount(comm, &n));
+        return n;
     }
 };
 
@@ -174,6 +182,7 @@ struct InprocTransport : Transport {
         return exchange(send, scnt, sdis, recv, rcnt, rdis, elem_bytes, include_self, st);
     }
     void abort() override { g->abort(); }
+    int size() override { return g->nranks; }
 };
 
 int grow(void** p, uint64_t* cap, uint64_t need, size_t elem, hipStream_t st) {
@@ -219,11 +228,17 @@ struct coala_comm {
     coala_comm_profile_t prof{};
     bool broken = false;
     // count exchanges issued ahead of their fetch (coala_comm_counts_begin): ring of device [2G] + pinned [2G] + event
-    static constexpr int kCountsRing = 8;
+    static constexpr int kCountsRing = COALA_COUNTS_RING;
     int64_t* ahead_dev = nullptr;   // [kCountsRing][2G]
     int64_t* ahead_host = nullptr;  // pinned [kCountsRing][2G]
     hipEvent_t ahead_ev[kCountsRing] = {};
     uint64_t ahead_calls = 0;
+    // The workspaces (recv_ids, rows_send, node/map) are ordered by the stream the fetches are enqueued on.  A caller that moves to
+    // another stream keeps that order: the new stream first waits (no host wait) for what the previous fetch enqueued on the old
+    // one -- the same rule as the cache handle's follow_stream.
+    hipStream_t order_stream = nullptr;
+    bool order_set = false;
+    hipEvent_t order_ev = nullptr;
 };
 
 namespace {
@@ -260,6 +275,18 @@ int finish_create(coala_comm* c) {
         return fail(COALA_ENOMEM, "communicator workspace allocation failed");
     for (int k = 0; k < coala_comm::kCountsRing; ++k)
         if (hipEventCreateWithFlags(&c->ahead_ev[k], hipEventDisableTiming) != hipSuccess) return fail(COALA_EHIP, "hipEventCreate failed");
+    return COALA_OK;
+}
+
+int follow_stream(coala_comm* c, hipStream_t s) {
+    if (c->order_set && c->order_stream != s) {
+        if (!c->order_ev) HIPCHK(hipEventCreateWithFlags(&c->order_ev, hipEventDisableTiming));
+        // (a stream the caller has destroyed in the meantime has nothing left to wait for)
+        if (hipEventRecord(c->order_ev, c->order_stream) == hipSuccess) HIPCHK(hipStreamWaitEvent(s, c->order_ev, 0));
+        else (void)hipGetLastError();
+    }
+    c->order_stream = s;
+    c->order_set = true;
     return COALA_OK;
 }
 
@@ -317,6 +344,15 @@ int coala_comm_create(const void* id_bytes, int rank, int nranks, int device, co
     if (r != ncclSuccess) {
         coala_comm_destroy(c);
         return fail(COALA_ECOMM, "ncclCommInitRank failed: %s", ncclGetErrorString(r));
+    }
+    {   // what RCCL itself thinks this communicator is: it must agree with what the caller asked for
+        int cnt = -1, urank = -1, dev = -1;
+        if (ncclCommCount(t->comm, &cnt) != ncclSuccess || ncclCommUserRank(t->comm, &urank) != ncclSuccess ||
+            ncclCommCuDevice(t->comm, &dev) != ncclSuccess || cnt != nranks || urank != rank || dev != device) {
+            coala_comm_destroy(c);
+            return fail(COALA_ECOMM, "RCCL reports %d ranks / rank %d / device %d for a communicator created as %d ranks / rank %d / device %d",
+                        cnt, urank, dev, nranks, rank, device);
+        }
     }
     if (int rc = finish_create(c)) {
         coala_comm_destroy(c);
@@ -402,6 +438,7 @@ int coala_comm_destroy(coala_comm_t* c) {
         if (c->ev_x[k]) (void)hipEventDestroy(c->ev_x[k]);
     }
     if (c->cs) (void)hipStreamDestroy(c->cs);
+    if (c->order_ev) (void)hipEventDestroy(c->order_ev);
     for (int k = 0; k < coala_comm::kCountsRing; ++k)
         if (c->ahead_ev[k]) (void)hipEventDestroy(c->ahead_ev[k]);
     if (c->ahead_host) (void)hipHostFree(c->ahead_host);
@@ -413,7 +450,7 @@ int coala_comm_destroy(coala_comm_t* c) {
     return COALA_OK;
 }
 
-int coala_comm_size(const coala_comm_t* c) { return c ? c->nranks : 0; }
+int coala_comm_size(const coala_comm_t* c) { return (c && c->tr) ? c->tr->size() : 0; }
 
 int coala_comm_set_rounds(coala_comm_t* c, int rounds) {
     if (!c || rounds < 1 || rounds > kMaxRounds) return fail(COALA_EINVAL, "rounds must be 1..%d", kMaxRounds);
@@ -465,14 +502,23 @@ int coala_comm_counts_begin(coala_comm_t* c, const int64_t* counts_dev, void* st
     if (c->ahead_calls >= coala_comm::kCountsRing) HIPCHK(hipEventSynchronize(c->ahead_ev[slot])); // the slot's previous exchange has landed
     int64_t* dev = c->ahead_dev + (size_t)slot * 2 * G;
     int64_t* host = c->ahead_host + (size_t)slot * 2 * G;
-    HIPCHK(hipMemcpyAsync(dev, counts_dev, (size_t)G * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
+    if (hipMemcpyAsync(dev, counts_dev, (size_t)G * sizeof(int64_t), hipMemcpyDeviceToDevice, st) != hipSuccess) {
+        c->broken = true; // the peers are about to enter the collective this rank will not join
+        c->tr->abort();
+        return fail(COALA_EHIP, "count exchange issued ahead: staging the counts failed: %s", hipGetErrorString(hipGetLastError()));
+    }
     if (int rc = c->tr->all_to_all_i64(dev, dev + G, st)) { // a collective: a failure here strands the peers -> abort
         c->broken = true;
         c->tr->abort();
         return rc;
     }
-    HIPCHK(hipMemcpyAsync(host, dev, 2 * (size_t)G * sizeof(int64_t), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipEventRecord(c->ahead_ev[slot], st));
+    // behind the collective a local failure must not leave this rank's ticket counter behind its peers': same path as fetch_impl
+    if (hipMemcpyAsync(host, dev, 2 * (size_t)G * sizeof(int64_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipEventRecord(c->ahead_ev[slot], st) != hipSuccess) {
+        c->broken = true;
+        c->tr->abort();
+        return fail(COALA_EHIP, "count exchange issued ahead: reading the counts back failed: %s", hipGetErrorString(hipGetLastError()));
+    }
     *ticket_out = (int64_t)c->ahead_calls++;
     return COALA_OK;
 }
@@ -506,6 +552,7 @@ static int fetch_impl(coala_cache_t* h, coala_comm_t* c, float* out, const int64
     const int64_t dim = coala_cache_row_dim(h);
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipSetDevice(c->device));
+    if ((rc = follow_stream(c, st))) return rc;
     const uint64_t nb = (uint64_t)(n > 0 ? n : 1);
     if (!bucketed) {
         if ((rc = grow((void**)&c->node, &c->node_cap, nb, sizeof(int64_t), st))) return rc;

@@ -98,7 +98,7 @@ inline bool is_space(char c) { return c == ' ' || c == '\t' || c == '\n' || c ==
 extern "C" {
 
 const char* coala_last_error(void) { return g_err; }
-int coala_abi_version(void) { return 2; }
+int coala_abi_version(void) { return 3; }
 
 // ------------------------------------------------------------------------------------------------ shm
 int coala_shm_open(const char* name, uint64_t bytes, int is_creator, int device, coala_shm_t** out) {
@@ -179,6 +179,12 @@ int coala_pinned_alloc(uint64_t bytes, int device, void** host_ptr, void** devic
 int coala_pinned_free(void* host_ptr) {
     if (!host_ptr) return COALA_OK;
     HIPCHK(hipHostFree(host_ptr));
+    return COALA_OK;
+}
+
+int coala_device_pci_bus_id(int device, char* out, size_t cap) {
+    if (!out || cap < 16) return fail(COALA_EINVAL, "the bus id needs a buffer of at least 16 bytes");
+    HIPCHK(hipDeviceGetPCIBusId(out, (int)cap, device));
     return COALA_OK;
 }
 

@@ -33,10 +33,14 @@ extern "C" {
 #define COALA_ECOMM (-7)    /* an RCCL call failed                             */
 
 #define COALA_WAYS 32u /* COALA_GNN_Modules/ssd_gnn_cache.cuh:61,204 */
+#define COALA_COUNTS_RING 8 /* count exchanges issued ahead (coala_comm_counts_begin) whose tickets stay valid */
 
 #define COALA_FLAG_SYNC 1u        /* synchronise the stream before returning (reference semantics)            */
 #define COALA_FLAG_DISTRIBUTED 2u /* set = (id / n_gpus) % sets   (nvshmem_cache.h:191-196,347) instead of id % sets */
 #define COALA_FLAG_PROFILE 4u     /* record hipEvents around the probe+gather kernel (see coala_cache_profile) */
+#define COALA_FLAG_TAG64 16u      /* keep the reference's 64-bit tags (a set = 32 x 8 B = two 128-B lines, isolated_cache.h:552) even when
+                                     num_rows < 2^32.  Default: 32-bit tags whenever every id fits -- a set is then ONE 128-B line, half
+                                     the probe bytes; coala_cache_dump widens them, so the visible table state is the same.            */
 #define COALA_FLAG_COLD_PARTITIONED 8u /* cold_table holds only this owner's rows: row k = node id k*n_gpus + rank, i.e. the
                                           cold row of id is id / n_gpus.  An owner of the partitioned cache never reads any
                                           other row, so each GPU pins 1/n_gpus of the table next to its own PCIe link instead
@@ -87,6 +91,8 @@ typedef struct coala_cache_geometry {
     uint32_t cache_dim;   /* floats per line */
     uint64_t line_bytes;  /* cache_dim * 4   */
     uint64_t table_bytes; /* HBM bytes held by lines + tags + metadata */
+    uint32_t tag_set_bytes; /* bytes of one set's 32 tags as stored: 128 (32-bit tags) or 256 (COALA_FLAG_TAG64 / num_rows >= 2^32) */
+    uint32_t reserved;
 } coala_cache_geometry_t;
 int coala_cache_geometry(const coala_cache_t* h, coala_cache_geometry_t* out);
 
@@ -166,6 +172,8 @@ int coala_comm_unique_id(void* out_id, size_t cap);
 /* ncclCommInitRank: collective over the nranks processes of the group (one process per GPU, RCCL over xGMI). */
 int coala_comm_create(const void* id_bytes, int rank, int nranks, int device, coala_comm_t** out);
 int coala_comm_destroy(coala_comm_t* c);
+/* Ranks of the communicator AS THE TRANSPORT SEES THEM: ncclCommCount for RCCL (and ncclCommUserRank is checked against `rank`
+ * at creation), the group size for the in-process transport.  Negative on failure. */
 int coala_comm_size(const coala_comm_t* c);
 /* In-process transport: the nranks ranks of a group are host THREADS of one process (one communicator each, any mix of
  * devices with peer access, several ranks per device allowed); ids and rows move with device-to-device copies ordered by
@@ -332,6 +340,10 @@ int coala_shm_close(coala_shm_t* s, int unlink);  /* SharedUVAManager::cleanup  
 /* Plain pinned host allocation visible to the device (private cold tier; hipHostMalloc mapped). */
 int coala_pinned_alloc(uint64_t bytes, int device, void** host_ptr, void** device_ptr);
 int coala_pinned_free(void* host_ptr);
+/* "dddd:bb:dd.f" of HIP device `device` (hipDeviceGetPCIBusId; initialises the runtime).  The host side places a rank's threads
+ * and its cold-tier shard on that GPU's NUMA node (COALA_GNN/numa.py reads /sys/bus/pci/devices/<id>/numa_node); the reference
+ * leaves the placement of its one shared segment to chance (COALA_GNN_Modules/shared_UVA.cuh:60-100). */
+int coala_device_pci_bus_id(int device, char* out, size_t cap);
 
 /* ------------------------------------------------------------------------------------------------------------
  * .npy reader and node distributor.  Replace parse_numpy_file / load_file_to_memory

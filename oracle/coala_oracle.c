@@ -8,6 +8,9 @@
 #include <ctype.h>
 #include <stdio.h>
 #include <stdlib.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <string.h>
 
 /* ---------------------------------------------------------------- geometry */
@@ -335,27 +338,50 @@ static uint64_t orc_sample_key(uint64_t seed, uint64_t step, int layer, uint64_t
     return orc_splitmix64(h ^ v);
 }
 
+static void orc_sample_row(const int64_t* indptr, const int64_t* indices, int64_t num_nodes, int64_t v, int fanout, uint64_t seed,
+                           uint64_t step, int layer, int64_t* row) {
+    if (v < 0 || v >= num_nodes) { for (int j = 0; j < fanout; ++j) row[j] = -1; return; }
+    int64_t start = indptr[v], deg = indptr[v + 1] - start;
+    if (deg <= fanout) { for (int j = 0; j < fanout; ++j) row[j] = j < deg ? indices[start + j] : -1; return; }
+    uint64_t key = orc_sample_key(seed, step, layer, (uint64_t)v);
+    int64_t chosen[32];
+    int c = 0;
+    for (int64_t j = deg - fanout; j < deg; ++j) { /* Floyd's subset sampling */
+        uint64_t r = orc_splitmix64(key + (uint64_t)c);
+        int64_t t = (int64_t)(((unsigned __int128)r * (unsigned __int128)(uint64_t)(j + 1)) >> 64);
+        int dup = 0;
+        for (int q = 0; q < c; ++q) dup |= (chosen[q] == t);
+        if (dup) t = j;
+        chosen[c++] = t;
+    }
+    for (int j = 0; j < fanout; ++j) row[j] = indices[start + chosen[j]];
+}
+
 void orc_sample_layer(const int64_t* indptr, const int64_t* indices, int64_t num_nodes, const int64_t* dst, int64_t n_dst,
                       int fanout, uint64_t seed, uint64_t step, int layer, int64_t* nbr) {
-    for (int64_t d = 0; d < n_dst; ++d) {
-        int64_t v = dst[d];
-        int64_t* row = nbr + d * fanout;
-        if (v < 0 || v >= num_nodes) { for (int j = 0; j < fanout; ++j) row[j] = -1; continue; }
-        int64_t start = indptr[v], deg = indptr[v + 1] - start;
-        if (deg <= fanout) { for (int j = 0; j < fanout; ++j) row[j] = j < deg ? indices[start + j] : -1; continue; }
-        uint64_t key = orc_sample_key(seed, step, layer, (uint64_t)v);
-        int64_t chosen[32];
-        int c = 0;
-        for (int64_t j = deg - fanout; j < deg; ++j) { /* Floyd's subset sampling */
-            uint64_t r = orc_splitmix64(key + (uint64_t)c);
-            int64_t t = (int64_t)(((unsigned __int128)r * (unsigned __int128)(uint64_t)(j + 1)) >> 64);
-            int dup = 0;
-            for (int q = 0; q < c; ++q) dup |= (chosen[q] == t);
-            if (dup) t = j;
-            chosen[c++] = t;
-        }
-        for (int j = 0; j < fanout; ++j) row[j] = indices[start + chosen[j]];
+    for (int64_t d = 0; d < n_dst; ++d) orc_sample_row(indptr, indices, num_nodes, dst[d], fanout, seed, step, layer, nbr + d * fanout);
+}
+
+/* The same layer with the destination nodes spread over `threads` host threads (OpenMP): the draw of a node depends only on
+ * (seed, step, layer, node), so the result is identical to orc_sample_layer's for any thread count.  bench.py's cpu_baseline times
+ * it beside the one-core call (the CPU sampler on all host cores).  Returns the number of threads OpenMP gave. */
+int orc_sample_layer_mt(const int64_t* indptr, const int64_t* indices, int64_t num_nodes, const int64_t* dst, int64_t n_dst,
+                        int fanout, uint64_t seed, uint64_t step, int layer, int64_t* nbr, int threads) {
+    int used = 1;
+#ifdef _OPENMP
+    if (threads < 1) threads = 1;
+#pragma omp parallel num_threads(threads)
+    {
+#pragma omp single
+        used = omp_get_num_threads();
+#pragma omp for schedule(static, 512)
+        for (int64_t d = 0; d < n_dst; ++d) orc_sample_row(indptr, indices, num_nodes, dst[d], fanout, seed, step, layer, nbr + d * fanout);
     }
+#else
+    (void)threads;
+    orc_sample_layer(indptr, indices, num_nodes, dst, n_dst, fanout, seed, step, layer, nbr);
+#endif
+    return used;
 }
 
 typedef struct { int64_t key; int32_t val; } orc_slot;
@@ -380,4 +406,76 @@ int64_t orc_compact_block(const int64_t* dst, int64_t n_dst, const int64_t* nbr,
     }
     free(tab);
     return n_src;
+}
+
+/* The same compaction on `threads` host threads (OpenMP), same result: (1) every item inserts its key into an open-addressing table
+ * (CAS on the key word) and lowers the slot's "first position" with an atomic min; (2) an item is a first appearance iff the slot's
+ * first position is its own; (3) a two-level prefix sum over the first-appearance flags numbers them in position order -- which IS
+ * the sequential scan's order; (4) every neighbour item reads its key's number.  Mirrors what coala_sampler.hip does on the GPU. */
+int64_t orc_compact_block_mt(const int64_t* dst, int64_t n_dst, const int64_t* nbr, int fanout, int64_t* src_out, int32_t* local, int threads) {
+#ifndef _OPENMP
+    (void)threads;
+    return orc_compact_block(dst, n_dst, nbr, fanout, src_out, local);
+#else
+    const int64_t n_items = n_dst * (fanout + 1);
+    if (threads < 1) threads = 1;
+    uint64_t cap = 16;
+    while (cap < 2 * (uint64_t)(n_items > 0 ? n_items : 1)) cap *= 2;
+    int64_t* tkey = (int64_t*)malloc(cap * sizeof(int64_t));
+    int64_t* tpos = (int64_t*)malloc(cap * sizeof(int64_t)); /* first position, then the local number */
+    uint32_t* slot_of = (uint32_t*)malloc((size_t)(n_items > 0 ? n_items : 1) * sizeof(uint32_t));
+    int64_t* part = (int64_t*)calloc((size_t)threads + 1, sizeof(int64_t));
+    int64_t n_src = 0;
+#pragma omp parallel num_threads(threads)
+    {
+        const int nt = omp_get_num_threads(), me = omp_get_thread_num();
+#pragma omp for schedule(static)
+        for (uint64_t i = 0; i < cap; ++i) { tkey[i] = -1; tpos[i] = INT64_MAX; }
+#pragma omp for schedule(static)
+        for (int64_t p = 0; p < n_items; ++p) {
+            const int64_t k = p < n_dst ? dst[p] : nbr[p - n_dst];
+            if (k < 0) { slot_of[p] = 0xFFFFFFFFu; continue; }
+            uint64_t sl = orc_splitmix64((uint64_t)k) & (cap - 1);
+            for (;;) {
+                int64_t cur = __atomic_load_n(&tkey[sl], __ATOMIC_RELAXED);
+                if (cur == -1) {
+                    int64_t expect = -1;
+                    if (__atomic_compare_exchange_n(&tkey[sl], &expect, k, 0, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) break;
+                    cur = expect;
+                }
+                if (cur == k) break;
+                sl = (sl + 1) & (cap - 1);
+            }
+            slot_of[p] = (uint32_t)sl;
+            int64_t seen = __atomic_load_n(&tpos[sl], __ATOMIC_RELAXED);
+            while (p < seen && !__atomic_compare_exchange_n(&tpos[sl], &seen, p, 0, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+        }
+        /* first appearances, numbered in position order: per-thread counts over contiguous ranges, then an exclusive scan */
+        const int64_t lo = n_items * me / nt, hi = n_items * (me + 1) / nt;
+        int64_t mine = 0;
+        for (int64_t p = lo; p < hi; ++p) mine += (slot_of[p] != 0xFFFFFFFFu && tpos[slot_of[p]] == p);
+        part[me + 1] = mine;
+#pragma omp barrier
+#pragma omp single
+        {
+            for (int t = 0; t < nt; ++t) part[t + 1] += part[t];
+            n_src = part[nt];
+        }
+        int64_t next = part[me];
+        for (int64_t p = lo; p < hi; ++p)
+            if (slot_of[p] != 0xFFFFFFFFu && tpos[slot_of[p]] == p) src_out[next++] = p < n_dst ? dst[p] : nbr[p - n_dst];
+#pragma omp barrier
+        /* the slot now carries the local number instead of the first position (every first appearance owns its slot) */
+        next = part[me];
+        for (int64_t p = lo; p < hi; ++p) {
+            const uint32_t sl = slot_of[p];
+            if (sl != 0xFFFFFFFFu && tpos[sl] == p) tpos[sl] = -(next++) - 1; /* negative: cannot be mistaken for a position */
+        }
+#pragma omp barrier
+#pragma omp for schedule(static)
+        for (int64_t p = n_dst; p < n_items; ++p) local[p - n_dst] = slot_of[p] == 0xFFFFFFFFu ? -1 : (int32_t)(-(tpos[slot_of[p]] + 1));
+    }
+    free(tkey); free(tpos); free(slot_of); free(part);
+    return n_src;
+#endif
 }

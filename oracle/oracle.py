@@ -73,8 +73,13 @@ def lib():
         L.orc_fill_features.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]
         L.orc_sample_layer.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_uint64,
                                        C.c_uint64, C.c_int, C.c_void_p]
+        L.orc_sample_layer_mt.restype = C.c_int
+        L.orc_sample_layer_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_uint64,
+                                          C.c_uint64, C.c_int, C.c_void_p, C.c_int]
         L.orc_compact_block.restype = C.c_int64
         L.orc_compact_block.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_compact_block_mt.restype = C.c_int64
+        L.orc_compact_block_mt.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         _lib = L
     return _lib
 
@@ -222,19 +227,28 @@ def distribute_node_with_affinity(items, offset, batch_size, local_size, node_id
     return out
 
 
-def sample_blocks(indptr, indices, seeds, fanouts_reversed, seed, step):
-    """Multi-layer twin of coala_sampler_sample: returns [(src_nodes int64[n_src], nbr_local int32[n_dst, f]), ...]."""
+def sample_blocks(indptr, indices, seeds, fanouts_reversed, seed, step, threads=1):
+    """Multi-layer twin of coala_sampler_sample: returns [(src_nodes int64[n_src], nbr_local int32[n_dst, f]), ...].
+    threads > 1: the draws of a layer are spread over that many OpenMP threads (same result: the RNG is counter-based); the
+    first-appearance compaction uses CAS inserts + a prefix sum and numbers the nodes exactly as the sequential scan does)."""
     indptr = np.ascontiguousarray(indptr, dtype=np.int64)
     indices = np.ascontiguousarray(indices, dtype=np.int64)
     dst = np.ascontiguousarray(seeds, dtype=np.int64)
     out = []
     for layer, f in enumerate(fanouts_reversed):
         nbr = np.empty(len(dst) * f, dtype=np.int64)
-        lib().orc_sample_layer(_ptr(indptr), _ptr(indices), len(indptr) - 1, _ptr(dst), len(dst), int(f), int(seed), int(step),
-                               layer, _ptr(nbr))
+        if threads > 1:
+            lib().orc_sample_layer_mt(_ptr(indptr), _ptr(indices), len(indptr) - 1, _ptr(dst), len(dst), int(f), int(seed), int(step),
+                                      layer, _ptr(nbr), int(threads))
+        else:
+            lib().orc_sample_layer(_ptr(indptr), _ptr(indices), len(indptr) - 1, _ptr(dst), len(dst), int(f), int(seed), int(step),
+                                   layer, _ptr(nbr))
         src = np.empty(len(dst) * (f + 1), dtype=np.int64)
         local = np.empty(len(dst) * f, dtype=np.int32)
-        n_src = lib().orc_compact_block(_ptr(dst), len(dst), _ptr(nbr), int(f), _ptr(src), _ptr(local))
+        if threads > 1:
+            n_src = lib().orc_compact_block_mt(_ptr(dst), len(dst), _ptr(nbr), int(f), _ptr(src), _ptr(local), int(threads))
+        else:
+            n_src = lib().orc_compact_block(_ptr(dst), len(dst), _ptr(nbr), int(f), _ptr(src), _ptr(local))
         src = src[:n_src].copy()
         out.append((src, local.reshape(len(dst), f), nbr.reshape(len(dst), f)))
         dst = src

@@ -36,7 +36,8 @@ def run(P, oracle, tmp_path, seed, cases=12):
             nd = P.Node_distributor_pybind(items.ctypes.data, 0, 1, 1, 1, files.color_file, files.topk_file, files.score_file)
         ctrl = P.SSD_GNN_SSD_Controllers(1, 4096, 1024, 0, 0, dim, True)
         cls = P.SSD_GNN_NVSHMEM_Cache if distributed else P.Isolated_Cache
-        cache = cls(ctrl, nd, 0, n_gpus, cache_mb, table.device_ptr, num_rows=num_rows, rank=0)
+        tag64 = bool(rng.integers(0, 2))   # the reference's 64-bit tags, or one 128-B line of 32-bit tags per set (the default)
+        cache = cls(ctrl, nd, 0, n_gpus, cache_mb, table.device_ptr, num_rows=num_rows, rank=0, tag64=tag64)
         orc = oracle.OracleCache(cache_mb, dim, feat, node_color=color, num_colors=num_colors if with_color else 0, n_gpus=n_gpus,
                                  distributed=distributed)
         bad_total = 0

@@ -66,6 +66,22 @@ def test_bench_two_ranks_on_one_gpu_with_epoch_leg():
     assert rp["chosen"] in (1, 2, 4) and set(rp["ms_per_fetch"]) == {"1", "2", "4"} and all(v > 0 for v in rp["ms_per_fetch"].values())
 
 
+def test_bench_one_rank_rccl_rehearsal():
+    """`bench.py --backend nccl` at N = 1: a torch.distributed world of one rank with RCCL for GPU tensors, the fused native exchange on
+    its OWN one-rank RCCL communicator (ranks as ncclCommCount reports them), sampler-bucketed ids, count exchanges issued ahead, and
+    the epoch leg under DistributedDataParallel (torch's RCCL communicator next to the exchange's) -- what the multi-GPU run does,
+    minus bytes on a link.  Runs on the driver's one-GPU box every round."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *SMALL, "--backend", "nccl", "--no-fanout-leg"], capture_output=True,
+                         text=True, timeout=900)
+    d = _line(out)
+    c = d["config"]
+    assert d["n_gpus"] == 1 and c["cache_backend"] == "nccl" and c["rccl_rehearsal_one_rank"] is True
+    assert c["exchange_transport"] == "native" and c["rccl_ranks"] == 1 and c["counts_ahead"] is True
+    assert "bucketed by owner" in c["input_nodes"] and d["value"] > 0 and 0 < d["roofline"]["frac"] < 1
+    e = d["epoch"]
+    assert "DistributedDataParallel" in e["model"] and e["serial"]["steps"] == 12 and e["prefetch"]["steps"] == 12
+
+
 def test_bench_rank_failure_is_visible():
     """A rank-local exception inside an extra leg must not strand the other ranks nor look like a success: rank 0 prints the
     line with an "error" field and the job ends with a non-zero exit code, quickly."""

@@ -47,7 +47,8 @@ def _compare_tables(cache, orc):
     (99, 1, 4000),     # dim % 4 != 0 -> scalar fallback path
     (1, 1, 3000),
 ])
-def test_read_feature_matches_oracle(hiplib, oracle, torch_cuda, tmp_path, dim, cache_mb, num_rows):
+@pytest.mark.parametrize("tag64", [False, True], ids=["tags32", "tags64"])   # one 128-B line per set (default below 2^32 rows) / the reference's 64-bit tags
+def test_read_feature_matches_oracle(hiplib, oracle, torch_cuda, tmp_path, dim, cache_mb, num_rows, tag64):
     torch = torch_cuda
     P = hiplib
     feat = oracle.make_features(num_rows, dim, seed=3)
@@ -55,10 +56,10 @@ def test_read_feature_matches_oracle(hiplib, oracle, torch_cuda, tmp_path, dim, 
     files = ColorFiles(tmp_path, color, tk, sc)
     items = np.arange(8, dtype=np.int64)
     table = PinnedTable(P, feat)
-    cache, nd = _make_cache(P, table, cache_mb, files, items)
+    cache, nd = _make_cache(P, table, cache_mb, files, items, tag64=tag64)
     orc = oracle.OracleCache(cache_mb, dim, feat, node_color=color, num_colors=12)
     g = cache.geometry()
-    assert (g.num_sets, g.cache_dim) == (orc.num_sets, orc.cache_dim)
+    assert (g.num_sets, g.cache_dim, g.tag_set_bytes) == (orc.num_sets, orc.cache_dim, 256 if tag64 else 128)
     rng = np.random.default_rng(7)
     sizes = [1, 3, 63, 64, 65, 257, 1000, min(4097, num_rows), min(2500, num_rows), 5]
     hot = rng.choice(num_rows, size=min(num_rows, 700), replace=False)  # a working set that produces hits
@@ -87,14 +88,15 @@ def test_read_feature_matches_oracle(hiplib, oracle, torch_cuda, tmp_path, dim, 
     table.close()
 
 
-def test_duplicates_empty_and_set_overflow(hiplib, oracle, torch_cuda):
+@pytest.mark.parametrize("tag64", [False, True], ids=["tags32", "tags64"])
+def test_duplicates_empty_and_set_overflow(hiplib, oracle, torch_cuda, tag64):
     """Duplicate ids inside a batch, an empty batch, and > 32 misses landing in one set within one batch."""
     torch = torch_cuda
     P = hiplib
     dim, num_rows, cache_mb = 1024, 4000, 1  # 8 sets x 32 ways
     feat = oracle.make_features(num_rows, dim, seed=11)
     table = PinnedTable(P, feat)
-    cache, _ = _make_cache(P, table, cache_mb)
+    cache, _ = _make_cache(P, table, cache_mb, tag64=tag64)
     orc = oracle.OracleCache(cache_mb, dim, feat)
     rng = np.random.default_rng(5)
     batches = [

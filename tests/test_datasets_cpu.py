@@ -95,3 +95,23 @@ def test_generate_color_data_tool(tmp_path):
     assert np.array_equal(np.load(out_dir / "color.npy"), color)
     assert np.array_equal(np.load(out_dir / "topk.npy"), tk) and np.array_equal(np.load(out_dir / "score.npy"), sc)
     assert tk.shape == (n_col, 10) and f"num_colors: {n_col}" in out.stdout
+
+
+def test_igb_large_and_full_label_files_and_masks(tmp_path, monkeypatch):
+    """IGB large / full keep node_label_19.npy as a HEADERLESS float32 file (the reference reads it with np.memmap,
+    examples/ssd_gnn_dataloader.py:381-387), and IGB-full's 60/20/20 masks run over its labelled prefix only (:527-546)."""
+    from COALA_GNN import datasets
+    n = 1000
+    lab = (np.arange(n) % 19).astype(np.float32)
+    p = tmp_path / "node_label_19.npy"
+    lab.tofile(p)                                              # no .npy header: np.load would refuse this file
+    labels, tr, va, te = datasets.load_labels_and_masks(str(p), n, "IGB", "large", 19)
+    assert labels.dtype == torch.int64 and np.array_equal(labels.numpy(), lab.astype(np.int64))
+    assert (int(tr.sum()), int(va.sum()), int(te.sum())) == (600, 200, 200) and bool(te[-1])
+    monkeypatch.setitem(datasets.IGB_FULL_LABELLED, 19, 500)   # stand-in for 227,130,858 of 269,346,174
+    labels, tr, va, te = datasets.load_labels_and_masks(str(p), n, "IGB", "full", 19)
+    assert (int(tr.sum()), int(va.sum()), int(te.sum())) == (300, 100, 100)
+    assert bool(tr[:300].all()) and bool(va[300:400].all()) and bool(te[400:500].all()) and not bool(te[500:].any())
+    np.save(tmp_path / "hdr.npy", lab.astype(np.int64))        # medium and smaller: a regular .npy, masks over every node
+    labels, tr, va, te = datasets.load_labels_and_masks(str(tmp_path / "hdr.npy"), n, "IGB", "medium", 19)
+    assert np.array_equal(labels.numpy(), lab.astype(np.int64)) and int(te.sum()) == 200

@@ -584,6 +584,68 @@ def test_split_serve_equals_one_serve(hiplib, oracle, dim, tier, monkeypatch):
         table.close()
 
 
+def test_counts_ahead_ticket_ring_exhaustion_falls_back(hiplib, oracle):
+    """More count exchanges issued ahead than the communicator's ring holds (COALA_COUNTS_RING = 8): the fetches whose tickets have
+    left the ring exchange their counts again, synchronously -- on every rank alike, since every rank makes the same calls -- and
+    deliver the same rows; the tickets still in the ring are used as issued."""
+    import ctypes as C
+    import threading
+    import torch
+    from COALA_GNN.COALA_GNN_Manager import NativeExchange
+    from COALA_GNN_Pybind import _capi
+    L = _capi.load()
+    G, dim, num_rows, steps = 2, 128, 8000, 11
+    assert _capi.COUNTS_RING == 8
+    feat, tables, caches, orcs = _dist_fixture(hiplib, oracle, G, dim, 1, True, num_rows, seed=21, cls="Isolated_Cache")
+    group = C.c_void_p()
+    _capi.check(L.coala_comm_group_create(G, C.byref(group)))
+    exs = [NativeExchange(None, 0, r, G, 0, inproc_group=group) for r in range(G)]
+    ids_seen = [[None] * G for _ in range(steps)]
+    used = [[None] * G for _ in range(steps)]
+    errors = []
+
+    def worker(r):
+        try:
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                batches = []
+                for step in range(steps):                                         # every count exchange goes out first ...
+                    ids = np.random.default_rng(40 * step + r).choice(num_rows, size=500 + 7 * step, replace=False)
+                    ids = np.concatenate([ids[ids % G == o] for o in range(G)]).astype(np.int64)
+                    cnt = torch.tensor([(ids % G == o).sum() for o in range(G)], dtype=torch.int64).cuda()
+                    batches.append((ids, torch.from_numpy(ids).cuda(), cnt, exs[r].counts_begin(cnt.data_ptr())))
+                for step, (ids, d_ids, cnt, ticket) in enumerate(batches):        # ... then the fetches, oldest ticket first
+                    out = torch.full((len(ids), dim), -3.0, dtype=torch.float32, device="cuda")
+                    used[step][r] = exs[r]._tickets - ticket <= _capi.COUNTS_RING
+                    exs[r].fetch_bucketed(caches[r], out.data_ptr(), d_ids.data_ptr(), len(ids), cnt.data_ptr(), ticket=ticket)
+                    torch.cuda.current_stream().synchronize()
+                    assert out.cpu().numpy().tobytes() == feat[ids].tobytes(), f"rank {r} step {step}"
+                    ids_seen[step][r] = ids
+        except BaseException as e:  # noqa: BLE001
+            errors.append((r, repr(e)))   # (the peer then times out on the in-process barrier: COALA_INPROC_TIMEOUT_S)
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(G)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    assert [u[0] for u in used] == [False] * 3 + [True] * 8 and all(u[0] == u[1] for u in used)   # 11 tickets, 8 slots: the first 3 fell back
+    for step in range(steps):
+        oracle.dist_fetch(orcs, ids_seen[step], oracle.SCHED_HITS_FIRST, want_rows=False)
+    for r in range(G):
+        assert caches[r].stats()[:2] == (orcs[r].hit_cnt, orcs[r].miss_cnt)
+        keys, cnt, _ = caches[r].dump()
+        assert np.array_equal(keys, orcs[r].keys()) and np.array_equal(cnt, orcs[r].set_cnt())
+    for e in exs:
+        e.close()
+    _capi.check(L.coala_comm_group_destroy(group))
+    for c in caches:
+        c.close()
+    for t in set(tables):
+        t.close()
+
+
 def test_native_fetch_over_rccl_two_gpus():
     """The fused native fetch over a REAL RCCL communicator between two distinct GPUs (bucketed and routed), against the table.
     Needs two visible GPUs: skipped on the one-GPU development / round-end boxes; it is what the driver's multi-GPU node exercises
@@ -611,6 +673,10 @@ def test_native_fetch_over_rccl_two_gpus():
 @pytest.mark.parametrize("name,dim,num_rows,cache_mb,fanout,avg_degree,steps", [
     ("IGB-medium 10,10, 4 GiB x 8 (configs[2])", 1024, 10_000_000, 4096, [10, 10], 10.5, 3),
     ("papers100M 15,10,5, 16 GiB x 8 (configs[3])", 128, 111_059_956, 16384, [15, 10, 5], 6.0, 2),
+    # configs[4]: the full table is 409.6 GB, the box's job may hold ~290 GB of host memory -> node count x 0.5 (SURVEY 8d allows a stated
+    # scale factor; examples/ssd_gnn_dataloader.py:375-376 for the shape).  Everything else is the configuration's: 16 GiB of cache per
+    # rank, 4-KiB lines, 131,072 sets per rank (nvshmem_cache.h:191-196), fan-out 10,10,10 at bs 1024, <= 1,362,944 rows per minibatch.
+    ("IGB-large 10,10,10, 16 GiB x 8 + host spill (configs[4]), rows x 0.5", 1024, 50_000_000, 16384, [10, 10, 10], 10.5, 2),
 ])
 def test_full_size_eight_inproc_ranks(hiplib, oracle, name, dim, num_rows, cache_mb, fanout, avg_degree, steps):
     """The 8-GPU configurations of BASELINE.json at full size on ONE MI355X: the whole table pinned on the host, partitioned by
@@ -618,8 +684,9 @@ def test_full_size_eight_inproc_ranks(hiplib, oracle, name, dim, num_rows, cache
     partitioned cache (8 x 4 GiB / 8 x 16 GiB of HBM), the configuration's fan-out at bs = 1024, sampler output bucketed by owner
     -> the native fused fetch.  Size-independent properties: every delivered row equals the procedural table bit for bit, a
     batch never exceeds the reference's max_sample (123,904 / 1,081,344 rows), owner counters and whole tag tables equal the
-    tag-only oracle fed with the same id lists, a second pass over the same minibatches is (almost) all hits.  (configs[4], IGB-large,
-    needs a 410 GB host table: beyond the box's host memory; its per-minibatch shape is covered by test_cache_gpu.py.)"""
+    tag-only oracle fed with the same id lists, a second pass over the same minibatches is (almost) all hits.  configs[4], IGB-large,
+    runs in the same distributed form with the node count scaled by 0.5 (8 shards of 25.6 GB = 204.8 GB pinned; the full 409.6 GB
+    table is beyond the host memory a job may hold on the box): max_sample 1,362,944 rows = 5.58 GB of output per rank and step."""
     import ctypes as C
     import threading
     import torch

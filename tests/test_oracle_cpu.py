@@ -145,3 +145,23 @@ def test_sampler_golden_and_properties(oracle, golden):
             assert np.array_equal((local >= 0).sum(1), np.minimum(deg, f))
             assert np.array_equal(src[local[local >= 0]], nbr[nbr >= 0])
             dst = src
+
+
+@pytest.mark.parametrize("threads", [2, 3, 8])
+def test_sampler_twin_is_thread_count_independent(oracle, golden, threads):
+    """The all-core CPU sampler of bench.py's cpu_baseline (OpenMP draws + CAS/prefix-sum compaction) returns exactly the blocks of
+    the one-core twin, golden vectors included, also with duplicated and out-of-range seeds."""
+    for case in golden["sampler"]:
+        d = np.load(os.path.join(GOLD, case["name"] + ".npz"))
+        args = (d["indptr"], d["indices"], d["seeds"], list(reversed(case["fanouts"])), case["rng_seed"], case["step"])
+        for a, b, want in zip(oracle.sample_blocks(*args), oracle.sample_blocks(*args, threads=threads), case["layers"]):
+            assert all(np.array_equal(x, y) for x, y in zip(a, b)) and sha(b[0]) == want["src_sha256"]
+    rng = np.random.default_rng(4)
+    n = 5000
+    deg = rng.integers(0, 30, size=n)
+    ip = np.zeros(n + 1, dtype=np.int64)
+    ip[1:] = np.cumsum(deg)
+    ix = rng.integers(0, n, size=int(ip[-1])).astype(np.int64)
+    seeds = rng.integers(-2, n + 2, size=700).astype(np.int64)       # duplicates, -1/-2 and n, n+1 (rejected: rows of -1)
+    for a, b in zip(oracle.sample_blocks(ip, ix, seeds, [7, 3], 9, 2), oracle.sample_blocks(ip, ix, seeds, [7, 3], 9, 2, threads=threads)):
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))

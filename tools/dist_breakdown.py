@@ -118,7 +118,7 @@ def timeit(fn, reps):
 
 
 row = dim * 4
-probe_b = tot * (8 + 256)
+probe_b = tot * (8 + 128)   # 32-bit tags: one 128-B line per set
 modes = {"before": [("route", route, 0), ("serve -> staging", serve_before, probe_b + 2 * tot * row),
                     ("self segment copy", self_copy, 2 * scnt[me] * row), ("un-permute all rows", scatter_before, 2 * n * row + 8 * n)],
          "after": [("route", route, 0), ("probe+fills (own shard -> out)", serve_after, probe_b + 2 * tot * row + 8 * scnt[me]),

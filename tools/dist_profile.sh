@@ -1,6 +1,9 @@
 #!/bin/bash
 # GPU box: device budget + measured HBM bytes (rocprofv3 PMC, separate passes) of one rank's share of an 8-way step,
 # round-1 sequence ("before") against the split-phase one ("after").  Output: gpurun_out/r02_dist_step_kernels.txt
+# the profiler's preloaded library starts the HIP runtime before python does: bench.py's os.environ.setdefault comes too late there,
+# so the queue count it reports has to be exported by the shell that starts the profiler
+export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-8}
 set -e
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/r02_dist_step_kernels.txt

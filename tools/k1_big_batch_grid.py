@@ -30,7 +30,7 @@ for dim, n, rows in ((1024, 123904, 2_000_000), (256, 262144, 4_000_000), (128, 
             p = cache.profile()
             us.append(round(p.gather_ms / max(p.gather_launches, 1) * 1e3, 1))
         t = sorted(us)[len(us) // 2]
-        alg = n * 264 + k * 2 * dim * 4
+        alg = n * (8 + cache.geometry().tag_set_bytes) + k * 2 * dim * 4
         print(f"{tag:28s} dim {dim:5d} n={n:8d} hit {hit:3d} %: K1 {t:8.2f} us = {alg / t / 1e3 / 80:5.1f} % of 8 TB/s   all: {us}", flush=True)
         cache.close()
     del table, out

@@ -8,15 +8,21 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "coala-gnn_amd")
 import torch
 import COALA_GNN_Pybind as P
 torch.cuda.set_device(0)
-print("# tools/k1_dim_sweep.py: K1 alone (HIP events attached to the launch: the kernel's own begin -> end), algorithmic bytes = rows x 264 B + hits x 2 x dim x 4 B")
-for dim, n, rows in ((128, 1081344, 8_000_000), (256, 262144, 4_000_000), (512, 123904, 4_000_000), (1024, 36864, 2_000_000), (1024, 123904, 2_000_000)):
+TAG64 = os.environ.get("TAG64") == "1"
+print(f"# tools/k1_dim_sweep.py: K1 alone (HIP events attached to the launch: the kernel's own begin -> end), algorithmic bytes = rows x (8 + {256 if TAG64 else 128}) B + hits x 2 x dim x 4 B  ({64 if TAG64 else 32}-bit tags)")
+SHAPES = ((128, 1081344, 8_000_000), (256, 262144, 4_000_000), (512, 123904, 4_000_000), (1024, 36864, 2_000_000), (1024, 123904, 2_000_000))
+if os.environ.get("SHAPES"):   # "dim:n:rows,dim:n:rows": other batch sizes / table sizes (CACHE_MB sets the cache size, default 4096)
+    SHAPES = tuple(tuple(int(x) for x in sh.split(":")) for sh in os.environ["SHAPES"].split(","))
+HITS = tuple(int(h) for h in os.environ.get("HITS", "0,25,32,50,75,90,100").split(","))
+for dim, n, rows in SHAPES:
     table = torch.rand((rows, dim), dtype=torch.float32, device="cuda")
     ctrl = P.SSD_GNN_SSD_Controllers(1, 4096, 1024, 0, 0, dim, True)
     perm = torch.randperm(rows, device="cuda")
     warm = perm[:n].contiguous()
     out = torch.empty((n, dim), dtype=torch.float32, device="cuda")
-    for hit in (0, 25, 32, 50, 75, 90, 100):   # 0.25 / 0.5 / 0.75 / 0.9, plus the default workload (0.32) and the two ends
-        cache = P.Isolated_Cache(ctrl, None, 0, 1, 4096, table.data_ptr(), num_rows=rows, profile=True, sync=False, max_batch=n)
+    for hit in HITS:   # 0.25 / 0.5 / 0.75 / 0.9, plus the default workload (0.32) and the two ends
+        cache = P.Isolated_Cache(ctrl, None, 0, 1, int(os.environ.get('CACHE_MB', 4096)), table.data_ptr(), num_rows=rows, profile=True, sync=False, max_batch=n, tag64=TAG64)
+        cache_tag_bytes = cache.geometry().tag_set_bytes
         cache.read_feature(out.data_ptr(), warm.data_ptr(), n)          # cache exactly the warm ids
         k = n * hit // 100
         # below 100 % the launch just timed caches its cold ids: every repetition takes fresh ones (as long as the sets stay far from
@@ -33,7 +39,7 @@ for dim, n, rows in ((128, 1081344, 8_000_000), (256, 262144, 4_000_000), (512, 
             p = cache.profile()
             us.append(p.gather_ms / max(p.gather_launches, 1) * 1e3)
         t = sorted(us)[len(us) // 2]
-        alg = n * 264 + k * 2 * dim * 4
+        alg = n * (8 + cache_tag_bytes) + k * 2 * dim * 4
         print(f"dim {dim:5d} n={n:8d} hit {hit:3d} %: K1 {t:8.2f} us   {alg / t / 1e3:7.1f} GB/s = {alg / t / 1e3 / 80:5.1f} % of 8 TB/s", flush=True)
         cache.close()
     del table

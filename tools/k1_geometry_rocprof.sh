@@ -1,6 +1,9 @@
 #!/bin/bash
 # GPU box: rocprofv3 durations of probe_gather_kernel in situ per launch geometry (tools/k1_insitu.py variants share one kernel
 # symbol: grouped by grid / workgroup size from the kernel trace, last 200 launches of each group = the timed minibatches).
+# the profiler's preloaded library starts the HIP runtime before python does: bench.py's os.environ.setdefault comes too late there,
+# so the queue count it reports has to be exported by the shell that starts the profiler
+export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-8}
 R=${GRAFT_REPO_ROOT:-$PWD}
 export TMPDIR=/tmp REPS=1
 cd /tmp

@@ -24,14 +24,20 @@ import COALA_GNN_Pybind as P  # noqa: E402
 from COALA_GNN.synthetic import PinnedFeatureTable, fill_table, powerlaw_csc  # noqa: E402
 from COALA_GNN.sampler import NeighborSampler  # noqa: E402
 
-rows, dim, batch, cache_mb = int(os.environ.get("ROWS", 10_000_000)), 1024, 1024, 4096
+# default: BASELINE configs[1] (IGB-medium 5,5, 4 GiB).  configs[3]'s shape (papers100M: 512-B lines, 16 GiB cache = a 134 MB tag table,
+# 289 k rows per minibatch at 62 % hits):  ROWS=111059956 DIM=128 FANOUT=15,10,5 CACHE_MB=16384 DEG=6
+rows, dim, batch, cache_mb = int(os.environ.get("ROWS", 10_000_000)), int(os.environ.get("DIM", 1024)), 1024, int(os.environ.get("CACHE_MB", 4096))
+fanout = [int(f) for f in os.environ.get("FANOUT", "5,5").split(",")]
+max_rows = batch
+for f in fanout:
+    max_rows *= f + 1
 torch.cuda.set_device(0)
 t0 = time.time()
 table = PinnedFeatureTable(rows, dim, 0)
 fill_table(table.cpu_tensor, 0, device="cuda:0")
-indptr, indices = powerlaw_csc(rows, 12.0, seed=0, device="cuda:0")
+indptr, indices = powerlaw_csc(rows, float(os.environ.get("DEG", 12.0)), seed=0, device="cuda:0")
 train_ids = torch.randperm(int(0.6 * rows), generator=torch.Generator().manual_seed(0))
-sampler = NeighborSampler([5, 5], seed=0)
+sampler = NeighborSampler(fanout, seed=0)
 graph = sampler.make_graph(indptr, indices)
 batches = [sampler.sample(graph, train_ids[s * batch: (s + 1) * batch].cuda(), step=s)[0] for s in range(620)]
 torch.cuda.synchronize()
@@ -41,6 +47,7 @@ if "--stages" in sys.argv:
     # where the fixed cost goes: K1's dependency chain cut after each link, launched right behind a real step's cold fill
     import ctypes as C
     from COALA_GNN_Pybind import current_stream
+    os.environ["COALA_K1_TAG64"] = "1"   # the stage kernels read the 64-bit tag layout
     L = C.CDLL(os.environ["COALA_HIP_LIB"])
     L.coala_dev_k1_stage.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
     cache = P.Isolated_Cache(ctrl := P.SSD_GNN_SSD_Controllers(1, 4096, 1024, 0, 0, dim, True), None, 0, 1, cache_mb, table.device_ptr, num_rows=rows,
@@ -67,7 +74,7 @@ if "--stages" in sys.argv:
         print(f"stage {stage:2d} {names[stage]:45s} mean {sum(us) / len(us):6.2f} us   median {us[len(us) // 2]:6.2f} us", flush=True)
     sys.exit(0)
 variants = [a for a in sys.argv[1:] if not a.startswith("--")] or ["GRID=2048"]
-out = torch.empty((36864, dim), dtype=torch.float32, device="cuda")
+out = torch.empty((max_rows, dim), dtype=torch.float32, device="cuda")
 for rep in range(int(os.environ.get("REPS", 2))):
     for v in variants:
         for k in list(os.environ):
@@ -77,7 +84,8 @@ for rep in range(int(os.environ.get("REPS", 2))):
             if kv:
                 k, val = kv.split("=")
                 os.environ["COALA_K1_" + k] = val
-        cache = P.Isolated_Cache(ctrl, None, 0, 1, cache_mb, table.device_ptr, num_rows=rows, profile=True, sync=False, max_batch=36864)
+        cache = P.Isolated_Cache(ctrl, None, 0, 1, cache_mb, table.device_ptr, num_rows=rows, profile=True, sync=False, max_batch=max_rows)
+        tagb = cache.geometry().tag_set_bytes
         for b in batches[:420]:
             cache.read_feature(out.data_ptr(), b.data_ptr(), b.numel())
         torch.cuda.synchronize()
@@ -94,12 +102,12 @@ for rep in range(int(os.environ.get("REPS", 2))):
         wall = (time.perf_counter() - t1) / 200 * 1e3
         p = cache.profile()
         hit, miss, _ = cache.stats()
-        alg = p.gather_rows * 264 + p.gather_hits * 2 * dim * 4
+        alg = p.gather_rows * (8 + tagb) + p.gather_hits * 2 * dim * 4
         us = p.gather_ms / p.gather_launches * 1e3
-        print(f"{v:40s} K1 {us:7.2f} us (events attached to the launch)  {alg / p.gather_launches / us / 1e3:7.1f} GB/s = "
+        print(f"{v:40s} tags {tagb} B/set  K1 {us:7.2f} us (events attached to the launch)  {alg / p.gather_launches / us / 1e3:7.1f} GB/s = "
               f"{alg / p.gather_launches / us / 1e3 / 80:5.1f} % of 8 TB/s   K2 {p.fill_ms / p.fill_launches * 1e3:8.1f} us   step {wall:.4f} ms   hit {hit / (hit + miss):.4f}", flush=True)
         if os.environ.get("ALLHIT"):   # the BASELINE section 4 micro-benchmark on the same handle: 36,864 unique ids, every row a hit
-            ids = torch.randperm(rows, device="cuda", generator=torch.Generator(device="cuda").manual_seed(12345))[:36864]
+            ids = torch.randperm(rows, device="cuda", generator=torch.Generator(device="cuda").manual_seed(12345))[:max_rows]
             for _ in range(3):
                 cache.read_feature(out.data_ptr(), ids.data_ptr(), ids.numel())
             torch.cuda.synchronize()
@@ -109,7 +117,7 @@ for rep in range(int(os.environ.get("REPS", 2))):
                 cache.read_feature(out.data_ptr(), ids.data_ptr(), ids.numel())
             torch.cuda.synchronize()
             p = cache.profile()
-            alg = p.gather_rows * 264 + p.gather_hits * 2 * dim * 4
+            alg = p.gather_rows * (8 + tagb) + p.gather_hits * 2 * dim * 4
             us = p.gather_ms / p.gather_launches * 1e3
-            print(f"{'  all-hit 36,864 rows':40s} K1 {us:7.2f} us   {alg / p.gather_launches / us / 1e3:7.1f} GB/s = {alg / p.gather_launches / us / 1e3 / 80:5.1f} % of 8 TB/s", flush=True)
+            print(f"{'  all-hit, max_sample rows':40s} K1 {us:7.2f} us   {alg / p.gather_launches / us / 1e3:7.1f} GB/s = {alg / p.gather_launches / us / 1e3 / 80:5.1f} % of 8 TB/s", flush=True)
         cache.close()

@@ -1,6 +1,9 @@
 #!/bin/bash
 # GPU box: rocprofv3 kernel trace of tools/k1_insitu.py --stages (K1's dependency chain cut after each link, launched behind a real
 # step's cold fill) -> per-kernel average durations, next to the HIP-event numbers the tool prints itself.
+# the profiler's preloaded library starts the HIP runtime before python does: bench.py's os.environ.setdefault comes too late there,
+# so the queue count it reports has to be exported by the shell that starts the profiler
+export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-8}
 set -e
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/r02_k1_fixed_cost.txt

@@ -2,6 +2,9 @@
 # GPU box: the prefetching loader under a training load -- tools/prefetch_probe.py (host-side split: consumer wait, producer
 # stages) run under rocprofv3 --kernel-trace --stats, so that the durations of the cache kernels in THAT context (cold fill beside
 # the training kernels) sit next to the host numbers.  Output: gpurun_out/r02_prefetch_epoch.txt
+# the profiler's preloaded library starts the HIP runtime before python does: bench.py's os.environ.setdefault comes too late there,
+# so the queue count it reports has to be exported by the shell that starts the profiler
+export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-8}
 set -e
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/r02_prefetch_epoch.txt

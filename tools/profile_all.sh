@@ -1,5 +1,8 @@
 #!/bin/bash
 # GPU box: everything under profiles/ for one round, in one go (about 4 GPU-minutes).  Summaries land in gpurun_out/profiles_out/.
+# the profiler's preloaded library starts the HIP runtime before python does: bench.py's os.environ.setdefault comes too late there,
+# so the queue count it reports has to be exported by the shell that starts the profiler
+export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-8}
 R=${GRAFT_REPO_ROOT:-$PWD}
 export ROUND=${ROUND:-r02} TMPDIR=/tmp
 O=$R/gpurun_out/profiles_out

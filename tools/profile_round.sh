@@ -3,6 +3,9 @@
 #   kernel trace + stats  -> per-kernel durations (must agree with bench.py's hipEvent numbers)
 #   --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (MI355X_MICROARCH.md: 3 + 2 TCC slots, not in one pass)
 # tools/summarize_profiles.py then writes the tracked summaries into profiles/.
+# the profiler's preloaded library starts the HIP runtime before python does: bench.py's os.environ.setdefault comes too late there,
+# so the queue count it reports has to be exported by the shell that starts the profiler
+export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-8}
 set -e
 R=${GRAFT_REPO_ROOT:-$PWD}
 ARGS="${BENCH_ARGS:---no-cpu-baseline --no-allhit --epoch-steps 0 --no-fanout-leg --no-color-affinity-leg}"   # the timed region only: the extra legs would add launches of the same kernels after it

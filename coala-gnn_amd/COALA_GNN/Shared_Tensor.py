@@ -183,12 +183,14 @@ class Shared_UVA_Tensor_Manager(object):
 
     def __init__(self, comm_manager, path, tensor_size: int):
         self.comm_manager = comm_manager
+        # the GPU this rank drives: its local rank (:129), unless the topology object pins another ordinal (several ranks on one GPU)
+        dev = int(getattr(comm_manager, "device_index", comm_manager.local_rank))
         self.memory_handle = SharedUVAManager(path, int(tensor_size), comm_manager.node_id, 0, 0,
-                                              local_rank=comm_manager.local_rank, barrier=comm_manager.local_comm.Barrier)
+                                              local_rank=comm_manager.local_rank, device=dev, barrier=comm_manager.local_comm.Barrier)
         self.tensor_size = int(tensor_size)
         self.device_ptr = self.memory_handle.get_device_ptr()
         self.host_ptr = self.memory_handle.get_host_ptr()
-        self.device = "cuda:" + str(comm_manager.local_rank)
+        self.device = "cuda:" + str(dev)
         self.owner = MemoryOwner()
 
     def get_tensor(self, dtype, device, tensor_shape):  # :141-150

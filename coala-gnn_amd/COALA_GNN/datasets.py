@@ -135,22 +135,46 @@ class SharedCSCDataset(object):
     over the labelled ones, :809-843) or "flat" (all files in root, IGB's split rule)."""
 
     def __init__(self, root, comm_manager, device, num_classes=19, in_memory=False, shm_name="/coala_shared_feat", layout="flat",
-                 dataset_size="experimental"):
+                 dataset_size="experimental", cold_tier="shm"):
+        """cold_tier: where the feature table lives.
+          "shm"         -- the reference's kind (:434-436): ONE POSIX shm segment per machine, mapped and hipHostRegister'ed by every
+                           local rank.  Measured on MI355X (profiles/r03_cold_tier_kinds.txt): 41 GB take 5.0 s to create + register
+                           (1.5 s per further mapping) and the zero-copy fill reads it 4 % slower than hipHostMalloc memory.
+          "private"     -- the whole table in this rank's own hipHostMalloc memory (1.7 s per 41 GB; the runtime places it on the
+                           GPU's NUMA node by itself): what an isolated cache on a single GPU should use.
+          "partitioned" -- only the rows this rank OWNS (id % local_size == local_rank) in its own hipHostMalloc memory, for the
+                           partitioned cache backends ("nccl" / "nvshmem"): 1/G of the memory per rank, next to the rank's own PCIe
+                           link.  Pass cold_partitioned=dataset.cold_partitioned to COALA_GNN_DataLoader."""
         self.root, self.comm, self.device = root, comm_manager, device
         paths = layout_paths(root, layout, dataset_size, num_classes)
         feat_mm = np.load(paths["feat"], mmap_mode=None if in_memory else "r")     # ssd_gnn_dataloader.py:418-423
         if feat_mm.dtype != np.float32 or feat_mm.ndim != 2:
             raise ValueError("node_feat.npy must be float32 [num_nodes, dim]")
+        if cold_tier not in ("shm", "private", "partitioned"):
+            raise ValueError("cold_tier must be 'shm', 'private' or 'partitioned'")
         self.num_nodes, self.dim = int(feat_mm.shape[0]), int(feat_mm.shape[1])
+        self.cold_tier, self.cold_partitioned = cold_tier, cold_tier == "partitioned"
         nbytes = self.num_nodes * self.dim * 4
-        self._shm = Shared_UVA_Tensor_Manager(comm_manager, shm_name, nbytes)        # :434
-        self.feat_data = self._shm.get_tensor(np.float32, device, (self.num_nodes, self.dim))   # :435
-        if comm_manager.local_rank == 0:                                             # :436 (streamed in 256 MiB pieces)
-            host = self._shm.get_host_array(np.float32, (self.num_nodes, self.dim))
-            step = max(1, (256 << 20) // (self.dim * 4))
-            for lo in range(0, self.num_nodes, step):
-                host[lo: lo + step] = feat_mm[lo: lo + step]
-        comm_manager.local_comm.Barrier()
+        step = max(1, (256 << 20) // (self.dim * 4))
+        self._shm = self._table = None
+        if cold_tier == "shm":
+            self._shm = Shared_UVA_Tensor_Manager(comm_manager, shm_name, nbytes)        # :434
+            self.feat_data = self._shm.get_tensor(np.float32, device, (self.num_nodes, self.dim))   # :435
+            if comm_manager.local_rank == 0:                                             # :436 (streamed in 256 MiB pieces)
+                host = self._shm.get_host_array(np.float32, (self.num_nodes, self.dim))
+                for lo in range(0, self.num_nodes, step):
+                    host[lo: lo + step] = feat_mm[lo: lo + step]
+            comm_manager.local_comm.Barrier()
+        else:
+            from .synthetic import PinnedFeatureTable
+            G, r = (comm_manager.local_size, comm_manager.local_rank) if self.cold_partitioned else (1, 0)
+            dev = int(getattr(comm_manager, "device_index", comm_manager.local_rank))
+            local_rows = (self.num_nodes - r + G - 1) // G
+            self._table = PinnedFeatureTable(local_rows, self.dim, dev)
+            for lo in range(0, local_rows, step):                                        # local row k holds node id k*G + r
+                hi = min(local_rows, lo + step)
+                self._table.array[lo:hi] = feat_mm[r + lo * G: r + hi * G: G]
+            self.feat_data = self._table                                                 # .data_ptr(): what sim_buf needs
         indptr, indices = load_csc_arrays(paths["graph_dir"], self.num_nodes, device=device)
         labels, train_mask, val_mask, test_mask = load_labels_and_masks(paths["label"], self.num_nodes, layout, dataset_size, num_classes)
         nd = {"label": labels.to(device), "labels": labels.to(device), "train_mask": train_mask, "val_mask": val_mask,
@@ -166,4 +190,7 @@ class SharedCSCDataset(object):
     def close(self):
         self.graph.close()
         self.feat_data = None
-        self._shm.cleanup()
+        if self._shm is not None:
+            self._shm.cleanup()
+        if self._table is not None:
+            self._table.close()

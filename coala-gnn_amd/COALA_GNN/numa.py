@@ -1,15 +1,22 @@
-"""NUMA placement of a rank: run its host threads -- and therefore allocate and pin its shard of the cold tier -- on the NUMA
+"""NUMA placement of a rank: run its host threads -- and first-touch whatever host memory it registers for the GPU -- on the NUMA
 node its GPU hangs off.
 
-The cold tier is zero-copy pinned host memory read by the GPU over PCIe.  Linux places memory on the node of the CPU that
-allocates / first touches it (default policy), so a rank that happens to run on the other socket pins its 5-50 GB shard there and
-every cold read crosses the inter-socket fabric before it reaches the GPU's root complex.  The reference pins ONE shared segment
-per machine and leaves its placement to whoever ran first (COALA_GNN_Modules/shared_UVA.cuh:42-100); the owner-partitioned tier
-here has one shard per GPU, so each can sit next to its own link.
+The cold tier is zero-copy pinned host memory read by the GPU over PCIe; a shard on the other socket is read across the
+inter-socket fabric before it reaches the GPU's root complex.  What decides where the memory lands depends on its kind
+(measured on a 2-socket MI355X host, profiles/r03_cold_tier_kinds.txt):
 
-No libnuma on the image: sysfs + os.sched_setaffinity only.  The GPU's PCI address is found WITHOUT touching the GPU (the binding
-has to happen before the HIP runtime starts its helper threads and before the first pinned allocation): KFD's topology lists the
-GPUs in the order HIP enumerates them; {ROCR,HIP,CUDA}_VISIBLE_DEVICES index lists are applied on top.
+  hipHostMalloc (coala_pinned_alloc, PinnedFeatureTable)   the runtime allocates from the pool of the GPU's OWN node, whatever CPU
+      asks: a rank deliberately bound to the far socket still got its 41 GB on the near node (K2 55.8 vs 55.7 GB/s) -- the
+      owner-partitioned tier of bench.py is placed correctly by construction.
+  POSIX shm + hipHostRegister (coala_shm_open, SharedUVAManager: the reference's kind, COALA_GNN_Modules/shared_UVA.cuh:60-100)
+      pages land where they are first touched / pinned: created by a process on the far socket the segment sits there and K2 reads
+      it at 52.4 instead of 53.5 GB/s.  The reference leaves this to whichever CPU its local rank 0 happens to run on.
+
+So the binding matters for the shared segment (local rank 0 creates and pins it: bind THAT rank first) and for the host threads that
+enqueue work and poll completion signals; it is harmless otherwise.  No libnuma on the image: sysfs + os.sched_setaffinity only.
+The GPU's PCI address is found WITHOUT touching the GPU (the binding has to happen before the HIP runtime starts its helper
+threads): KFD's topology lists the GPUs in the order HIP enumerates them; {ROCR,HIP,CUDA}_VISIBLE_DEVICES index lists are applied
+on top (cross-checked against hipDeviceGetPCIBusId by tools/host_probe.py).
 
     COALA_NUMA = auto (default) | off | far | <node number>
        far: the node FURTHEST from the GPU's (tools/numa_probe.sh: the deliberate wrong placement, to measure what it costs)
@@ -20,6 +27,7 @@ import os
 __all__ = ["bind_to_device_node", "describe", "device_pci_address", "pci_bus_id_of_device", "current_placement"]
 
 _applied = None   # what bind_to_device_node did in this process (bench.py reports it)
+_SYS = "/sys"     # (tests point this at a fake tree)
 
 
 def _read(path, default=None):
@@ -47,7 +55,7 @@ def _parse_cpulist(s):
 def _kfd_gpus():
     """PCI addresses of the GPUs in KFD node order (= HIP's enumeration order before the *_VISIBLE_DEVICES filters)."""
     out = []
-    nodes = sorted(glob.glob("/sys/class/kfd/kfd/topology/nodes/[0-9]*"), key=lambda p: int(os.path.basename(p)))
+    nodes = sorted(glob.glob(_SYS + "/class/kfd/kfd/topology/nodes/[0-9]*"), key=lambda p: int(os.path.basename(p)))
     for n in nodes:
         props = {}
         for line in (_read(os.path.join(n, "properties"), "") or "").splitlines():
@@ -85,7 +93,7 @@ def device_pci_address(device_index):
     gpus = _visible(_kfd_gpus())
     if gpus and 0 <= int(device_index) < len(gpus):
         return gpus[int(device_index)]
-    cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"), key=lambda p: int(os.path.basename(os.path.dirname(p))[4:]))
+    cards = sorted(glob.glob(_SYS + "/class/drm/card[0-9]*/device"), key=lambda p: int(os.path.basename(os.path.dirname(p))[4:]))
     cards = [c for c in cards if _read(os.path.join(c, "vendor")) == "0x1002"]
     if len(cards) == 1 and int(device_index) == 0:   # a one-GPU box: nothing to get wrong
         return os.path.basename(os.path.realpath(cards[0]))
@@ -95,7 +103,7 @@ def device_pci_address(device_index):
 def _node_of_pci(addr):
     if not addr:
         return None
-    v = _read(f"/sys/bus/pci/devices/{addr}/numa_node")
+    v = _read(f"{_SYS}/bus/pci/devices/{addr}/numa_node")
     try:
         v = int(v)
     except (TypeError, ValueError):
@@ -105,13 +113,13 @@ def _node_of_pci(addr):
 
 def _nodes():
     res = {}
-    for d in glob.glob("/sys/devices/system/node/node[0-9]*"):
+    for d in glob.glob(_SYS + "/devices/system/node/node[0-9]*"):
         res[int(os.path.basename(d)[4:])] = _parse_cpulist(_read(os.path.join(d, "cpulist"), ""))
     return res
 
 
 def _far_node(near, nodes):
-    dist = (_read(f"/sys/devices/system/node/node{near}/distance", "") or "").split()
+    dist = (_read(f"{_SYS}/devices/system/node/node{near}/distance", "") or "").split()
     best, best_d = None, -1
     for n in sorted(nodes):
         if n == near or not nodes[n]:

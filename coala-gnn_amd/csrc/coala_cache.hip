@@ -174,10 +174,12 @@ struct Geo {
 #ifndef K1_MIN_WAVES
 #define K1_MIN_WAVES 4 // waves per SIMD the register allocator must leave room for
 #endif
-// Row(-pair)s a wave keeps in flight with 32-bit tags, by line size (the 64-bit layout keeps 4: its probe state is twice as wide).
-// Bytes in flight per wave = NP x rows per pass x line: 16 KiB for 4-KiB lines; short lines get more passes so that a wave that
-// runs ONE chunk (the usual case: the grid is one chunk per wave up to 131 k rows) still has several KiB outstanding.
-constexpr int k1_np32(int cd) { return cd >= 512 ? 4 : 8; }
+// Row(-pair)s a wave keeps in flight (passes): 4 for every line size and both tag widths = 16 KiB of 4-KiB lines, 4 KiB of 512-B lines
+// (8 rows).  More passes on short lines were measured in situ on the configs[3] shape (512-B lines, 16 GiB cache, 315 k rows per
+// minibatch at 62 % hits; tools/k1_insitu.py, profiles/r03_k1_insitu_papers100m.txt): 2 / 4 / 8 / 16 passes -> 51.2 / 51.0 / 53.4 /
+// (72 k rows) 44.5 us: a launch of this size is one chunk per wave, so its waves overlap each other, not their own chunks, and fewer,
+// fatter waves lose more parallelism than they gain bytes in flight.
+constexpr int k1_np32(int /*cache_dim*/) { return 4; }
 constexpr int kK1Waves = 2; // waves per block (measured: 2048 x 128 threads beats 1024 x 256 and 256 x 1024 by 3-20 %)
 #ifdef COALA_DEV_KNOBS          // development builds only (build.py --dev -> libcoala_hip_dev.so): launch geometry from the environment
 constexpr int kK1MaxWaves = 4;
@@ -456,15 +458,17 @@ __global__ __launch_bounds__(256) void miss_fill_kernel(CacheDev c, const int64_
     const int l_in = lane & (G::LPR - 1);
     uint32_t my_miss = 0, my_bad = 0;
 
-    constexpr int U = 4; // verdict loads in flight per wave: the scan of a batch without misses is a chain of load latencies
+    // U verdict loads in flight per wave: the scan of a batch without misses is a chain of load latencies, and with FEW misses every
+    // group of U tiles is ranked and streamed as one (below) -- 8 tiles = 512 rows per step (4 until round 3: 2 % misses 56 -> 5x us)
+    constexpr int U = 8;
     for (int64_t tile0 = wave; tile0 < n_tiles; tile0 += n_waves * U) {
-      uint32_t st_pack = 0; // the U verdict bytes of this lane, one per tile
+      uint64_t st_pack = 0; // the U verdict bytes of this lane, one per tile
 #pragma unroll
       for (int u = 0; u < U; ++u) {
           const int64_t tile = tile0 + u * n_waves;
           const uint32_t p = (tile < n_tiles && lane < tile_rows) ? pos_of(rs, (uint32_t)(tile * tile_rows + lane)) : 0xFFFFFFFFu;
           const uint32_t w = (p != 0xFFFFFFFFu) ? c.miss_link[p] : 0u;
-          const uint32_t v = (w == 0u) ? 0u : ((w & kLinkMiss) ? 1u : 2u);
+          const uint64_t v = (w == 0u) ? 0u : ((w & kLinkMiss) ? 1u : 2u);
           st_pack |= v << (8 * u);
       }
       if (!__ballot(st_pack != 0)) continue; // nothing but hits in these U tiles

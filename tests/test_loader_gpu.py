@@ -117,6 +117,37 @@ def test_shared_csc_dataset_from_npy(hiplib, oracle, tmp_path):
     ds.close()
 
 
+@pytest.mark.parametrize("cold_tier", ["private", "partitioned"])
+def test_shared_csc_dataset_private_cold_tiers(hiplib, oracle, tmp_path, cold_tier):
+    """The faster cold-tier kinds of SharedCSCDataset (hipHostMalloc instead of shm + hipHostRegister): the whole table private to the
+    rank, or only the rows the rank owns (here: rank 1 of a 3-rank machine) behind a partitioned cache shard."""
+    import torch
+    from COALA_GNN.datasets import SharedCSCDataset
+    rng = np.random.default_rng(1)
+    n, dim = 2999, 128
+    deg = rng.integers(1, 6, size=n)
+    indptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    np.save(tmp_path / "csc_indptr.npy", indptr); np.save(tmp_path / "csc_indices.npy", rng.integers(0, n, size=int(indptr[-1])).astype(np.int64))
+    feat = oracle.make_features(n, dim, seed=9)
+    np.save(tmp_path / "node_feat.npy", feat); np.save(tmp_path / "node_label_19.npy", (np.arange(n) % 19).astype(np.int64))
+
+    class Comm:     # the topology a rank of a 3-GPU machine would see (no process group needed for these tiers)
+        node_id, local_rank, local_size, device_index = 0, (1 if cold_tier == "partitioned" else 0), (3 if cold_tier == "partitioned" else 1), 0
+    ds = SharedCSCDataset(str(tmp_path), Comm(), "cuda:0", cold_tier=cold_tier)
+    G, r = Comm.local_size, Comm.local_rank
+    assert ds.cold_partitioned == (cold_tier == "partitioned") and ds.feat_data.rows == len(range(r, n, G))
+    assert np.array_equal(ds.feat_data.array, feat[r::G])
+    P = hiplib
+    ctrl = P.SSD_GNN_SSD_Controllers(1, 4096, 1024, 0, 0, dim, True)
+    cache = P.Isolated_Cache(ctrl, None, r, G, 1, ds.feat_data.data_ptr(), num_rows=n, rank=r, cold_partitioned=ds.cold_partitioned)
+    ids = np.arange(r, n, G)[::3].astype(np.int64)            # ids this owner serves
+    out = torch.empty((len(ids), dim), dtype=torch.float32, device="cuda")
+    (cache.serve if G > 1 else cache.read_feature)(out.data_ptr(), torch.from_numpy(ids).cuda().data_ptr(), len(ids))
+    assert out.cpu().numpy().tobytes() == feat[ids].tobytes()
+    cache.close()
+    ds.close()
+
+
 def test_example_training_script_runs():
     """examples/train_synthetic.py: the reference's training loop on the API mirror, end to end (colouring tool included)."""
     root = os.path.dirname(HERE)

@@ -4,12 +4,14 @@
 # so the queue count it reports has to be exported by the shell that starts the profiler
 export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-8}
 R=${GRAFT_REPO_ROOT:-$PWD}
-export ROUND=${ROUND:-r02} TMPDIR=/tmp
+export ROUND=${ROUND:-r03} TMPDIR=/tmp
 O=$R/gpurun_out/profiles_out
 mkdir -p $O
 cd $R
 bash tools/profile_round.sh > $R/gpurun_out/profile_default.log 2>&1; echo "default profile rc=$?"
 TAG=allhit BENCH_ARGS="--rows 2000000 --mode allhit --prewarm 3 --steps 100 --no-cpu-baseline --epoch-steps 0 --no-fanout-leg --no-color-affinity-leg" bash tools/profile_round.sh > $R/gpurun_out/profile_allhit.log 2>&1; echo "allhit profile rc=$?"
+# BASELINE configs[3]'s single-GPU shape (512-B lines, 16 GiB cache): kernel trace + the two PMC passes for probe_gather_kernel<128, ...>
+TAG=papers100m BENCH_ARGS="--rows 111059956 --dim 128 --fanout 15,10,5 --cache-mb 16384 --no-cpu-baseline --no-allhit --epoch-steps 0 --no-fanout-leg --no-color-affinity-leg" bash tools/profile_round.sh > $R/gpurun_out/profile_papers100m.log 2>&1; echo "papers100m profile rc=$?"
 bash tools/dist_profile.sh > /dev/null 2>&1; grep -v amdgpu.ids $R/gpurun_out/r02_dist_step_kernels.txt > $O/${ROUND}_dist_step_kernels.txt; echo "dist rc=$?"
 COALA_K1_GRID=8192 bash tools/k1_stages_profile.sh > /dev/null 2>&1; grep -v "amdgpu.ids\|^[EW]2026" $R/gpurun_out/r02_k1_fixed_cost.txt > $O/${ROUND}_k1_fixed_cost.txt; echo "k1 stages rc=$?"
 bash tools/k1_variants.sh > /dev/null 2>&1; cp $R/gpurun_out/r02_k1_variants.txt $O/${ROUND}_k1_variants.txt; echo "k1 variants rc=$?"

@@ -187,6 +187,8 @@ constexpr int kK1MaxWaves = 4;
 constexpr int kK1MaxWaves = kK1Waves;
 #endif
 
+__device__ __forceinline__ float first_of(float v) { return v; }
+__device__ __forceinline__ float first_of(vfloat4 v) { return v.x; }
 template <typename V> __device__ __forceinline__ V nt_load(const V* p) { return __builtin_nontemporal_load(p); }
 template <typename V> __device__ __forceinline__ void nt_store(V v, V* p) { __builtin_nontemporal_store(v, p); }
 // K1's row moves: nontemporal loads of the lines (touched once per batch: keeps them from displacing the tag sets; plain loads are
@@ -208,7 +210,10 @@ template <typename V> __device__ __forceinline__ void k1_store(V v, V* p) {
 #endif
 }
 
-template <int CD, int VEC, typename TAG, int NP = 4, bool FULL = false, int NOMISS = 0 /* development only: 1 = no miss bookkeeping */, bool REDIR = false>
+// NOMISS is a development switch (tools/k1_insitu.py --stages: where a launch's time goes; such launches run on a generation nobody
+// consumes): 0 = the product kernel; 1 = no miss bookkeeping; 11 / 12 / 13 = the dependency chain cut short after the id loads /
+// after the tag loads and ballots / after the line loads of the hit rows (no stores).
+template <int CD, int VEC, typename TAG, int NP = 4, bool FULL = false, int NOMISS = 0, bool REDIR = false>
 __global__ __launch_bounds__(64 * kK1MaxWaves, K1_MIN_WAVES) void probe_gather_kernel(const int64_t* __restrict__ idx, float* __restrict__ out,
                                                                     int64_t n, uint32_t gen, uint32_t n_blocks, CacheDev c, Redirect rd) {
     // Argument order and the explicit block count are deliberate: with kernarg preloading (build.py: -mllvm -amdgpu-kernarg-preload-count=16)
@@ -272,6 +277,10 @@ __global__ __launch_bounds__(64 * kK1MaxWaves, K1_MIN_WAVES) void probe_gather_k
 
     int64_t chunk = wave;
     Ids ids_next = load_ids(chunk);
+    if (NOMISS == 11) { // (development) ids only
+        if (ids_next.id[0] == 0x7FFFFFFFFFFFFFF1ull) out[0] = 1.f;
+        return;
+    }
     Tags tags = load_tags(ids_next);
     ids_next = load_ids(chunk + n_waves);
 
@@ -325,8 +334,12 @@ __global__ __launch_bounds__(64 * kK1MaxWaves, K1_MIN_WAVES) void probe_gather_k
                 }
             }
         }
+        if (NOMISS == 12) { // (development) ids + tag sets + ballots
+            if ((hitmask ^ (missmask << 1) ^ my_set) == 0xFFFFFFF7u) out[0] = 1.f;
+            return;
+        }
         // ---- misses: push the row on its set's chain (the old head comes back behind the row loads)
-        const bool i_miss = NOMISS != 1 && lane < R && ((missmask >> lane) & 1);
+        const bool i_miss = NOMISS == 0 && lane < R && ((missmask >> lane) & 1);
         unsigned long long prev = 0;
         if (i_miss) {
             const unsigned long long tag = ((unsigned long long)gen << 32) | (unsigned long long)(base + lane + 1);
@@ -354,6 +367,18 @@ __global__ __launch_bounds__(64 * kK1MaxWaves, K1_MIN_WAVES) void probe_gather_k
                 if (h && (FULL || u < nunits)) val[p][v] = k1_load(src + u);
             }
         }
+        if (NOMISS == 13) { // (development) + the line loads of the hit rows, nothing stored
+            float acc = 0.f;
+#pragma unroll
+            for (int p = 0; p < G::PASSES; ++p) {
+                const bool h = (hitmask >> (p * G::RPP + sub)) & 1;
+#pragma unroll
+                for (int v = 0; v < G::VPL; ++v)
+                    if (h && (FULL || (uint32_t)(v * G::LPR + l_in) < nunits)) acc += first_of(val[p][v]);
+            }
+            if (acc == 123456.789f) out[0] = acc;
+            return;
+        }
         tags = load_tags(ids_next);
         ids_next = ids_next2;
 #pragma unroll
@@ -377,7 +402,7 @@ __global__ __launch_bounds__(64 * kK1MaxWaves, K1_MIN_WAVES) void probe_gather_k
         }
         // ---- verdict for K2: one word per position, written for EVERY row of the chunk (one 4-byte store per lane q < R), so the
         //      array never needs clearing between batches
-        if (NOMISS != 1 && lane < R && base + lane < n) {
+        if (NOMISS == 0 && lane < R && base + lane < n) {
             uint32_t w = 0u;
             if (i_miss) w = kLinkMiss | (((uint32_t)(prev >> 32) == gen) ? (uint32_t)prev : 0u);
             else if ((badmask >> lane) & 1) w = kLinkBad;
@@ -387,43 +412,8 @@ __global__ __launch_bounds__(64 * kK1MaxWaves, K1_MIN_WAVES) void probe_gather_k
 }
 
 #ifdef COALA_DEV_KNOBS
-// Development only (tools/k1_insitu.py --stages): the prologue of K1 cut short after each link of its dependency chain, one chunk
-// per wave, to see where the fixed cost of a launch goes.  STAGE 0: nothing; 1: ids; 2: ids + tags + ballots; 3: + the line loads
-// of the hit rows (no stores).
-template <int STAGE>
-__global__ __launch_bounds__(256, K1_MIN_WAVES) void k1_stage_kernel(const int64_t* __restrict__ idx, float* __restrict__ out, int64_t n,
-                                                                     CacheDev c) {
-    if (STAGE == 0) return;
-    const int lane = threadIdx.x & 63;
-    const int64_t chunk = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int64_t i_l = chunk * 4 + (lane >> 4);
-    const uint64_t id = (i_l < n) ? (uint64_t)idx[i_l] : 0;
-    if (STAGE == 1) {
-        if (id == 0x7FFFFFFFFFFFFFF1ull) out[0] = 1.f;
-        return;
-    }
-    const bool ok = i_l < n && id < c.num_rows;
-    const uint64_t set = ok ? set_of(c, id) : 0;
-    vu64x2 kk = vu64x2{kEmptyKey, kEmptyKey};
-    if (ok) kk = *reinterpret_cast<const vu64x2*>(reinterpret_cast<const uint64_t*>(c.keys) + set * COALA_WAYS + (lane & 15) * 2); // 64-bit tag layout only (COALA_FLAG_TAG64)
-    const uint64_t m0 = __ballot(ok && kk.x == id), m1 = __ballot(ok && kk.y == id);
-    if (STAGE == 2) {
-        if ((m0 ^ m1) == 0x123456789ABCDEFull) out[0] = 1.f;
-        return;
-    }
-    vfloat4 acc = vfloat4{0.f, 0.f, 0.f, 0.f};
-    for (int q = 0; q < 4; ++q) {
-        const uint32_t a = (uint32_t)(m0 >> (16 * q)) & 0xFFFFu, b = (uint32_t)(m1 >> (16 * q)) & 0xFFFFu;
-        if (a | b) {
-            const int j = __builtin_ctz(a | b);
-            const uint32_t way = 2 * j + (((a >> j) & 1) ? 0 : 1);
-            const uint64_t set_q = readlane64(set, 16 * q);
-            const vfloat4* src = reinterpret_cast<const vfloat4*>(c.lines + (set_q * COALA_WAYS + way) * 1024);
-            for (int v = 0; v < 4; ++v) acc += nt_load(src + v * 64 + lane);
-        }
-    }
-    if (acc.x == 123456.789f) out[0] = acc.y;
-}
+// Development only (tools/k1_insitu.py --stages): the launch + drain cost of K1's grid with nothing in it.
+__global__ __launch_bounds__(64 * kK1MaxWaves, K1_MIN_WAVES) void k1_empty_kernel() {}
 #endif
 
 // ---------------------------------------------------------------------------------------------------------- K2
@@ -1223,7 +1213,8 @@ static int read_feature_impl(coala_cache_t* h, float* out, const int64_t* idx, i
                 using GR = Geo<CD, VEC, NPR>;
                 const int64_t chunks = redir ? (n + GR::R - 1) / GR::R : (n + GK::R - 1) / GK::R;
                 const dim3 grid(grid_for(chunks, h->k1_waves, h->k1_grid_cap)), block(64 * h->k1_waves);
-                if (redir) ps.launch(probe_gather_kernel<CD, VEC, TAG, NPR, false, 0, true>, grid, block, idx, out, n, gen, (uint32_t)grid.x, d, rd);
+                if (redir && full) ps.launch(probe_gather_kernel<CD, VEC, TAG, NPR, true, 0, true>, grid, block, idx, out, n, gen, (uint32_t)grid.x, d, rd);
+                else if (redir) ps.launch(probe_gather_kernel<CD, VEC, TAG, NPR, false, 0, true>, grid, block, idx, out, n, gen, (uint32_t)grid.x, d, rd);
                 else if (full) ps.launch(probe_gather_kernel<CD, VEC, TAG, NP, true>, grid, block, idx, out, n, gen, (uint32_t)grid.x, d, rd);
                 else ps.launch(probe_gather_kernel<CD, VEC, TAG, NP, false>, grid, block, idx, out, n, gen, (uint32_t)grid.x, d, rd);
             };
@@ -1383,22 +1374,32 @@ int coala_cache_scatter(coala_cache_t* h, float* out, const float* src, const in
 }
 
 #ifdef COALA_DEV_KNOBS
-int coala_dev_k1_stage(coala_cache_t* h, float* out, const int64_t* idx, int64_t n, int stage, void* stream) { // not part of the ABI
+// not part of the ABI.  stage 0: empty kernel on K1's grid; 1: + ids; 2: + tag sets, ballots; 3: + line loads of the hit rows (no stores);
+// 4: the product kernel without miss bookkeeping; 5: the product kernel (on a generation nobody consumes).  Any line size / tag width.
+int coala_dev_k1_stage(coala_cache_t* h, float* out, const int64_t* idx, int64_t n, int stage, void* stream) {
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid((unsigned)((n + 7) / 8)), block(128);
-    switch (stage) {
-        case 0: hipLaunchKernelGGL(k1_stage_kernel<0>, grid, block, 0, s, idx, out, n, h->d); break;
-        case 1: hipLaunchKernelGGL(k1_stage_kernel<1>, grid, block, 0, s, idx, out, n, h->d); break;
-        case 2: hipLaunchKernelGGL(k1_stage_kernel<2>, grid, block, 0, s, idx, out, n, h->d); break;
-        case 3: hipLaunchKernelGGL(k1_stage_kernel<3>, grid, block, 0, s, idx, out, n, h->d); break;
-        case 4: // the product kernel without the miss bookkeeping (hits copied, misses ignored)
-            hipLaunchKernelGGL((probe_gather_kernel<1024, 4, uint64_t, 4, true, 1>), grid, block, 0, s, idx, out, n, 0xFFFFFFF0u, grid.x, h->d, Redirect{0, 0, nullptr, nullptr});
-            break;
-        default: // the product kernel itself on a generation nobody consumes
-            hipLaunchKernelGGL((probe_gather_kernel<1024, 4, uint64_t, 4, true, 0>), grid, block, 0, s, idx, out, n, 0xFFFFFFF1u, grid.x, h->d, Redirect{0, 0, nullptr, nullptr});
-            break;
-    }
-    return COALA_OK;
+    CacheDev d = h->d;
+    return dispatch_geo(d.cache_dim, true, [&](auto geo) -> int {
+        constexpr int CD = geo_cd(geo);
+        constexpr int VEC = geo_vec(geo);
+        using GK = Geo<CD, VEC, 4>;
+        const int64_t chunks = (n + GK::R - 1) / GK::R;
+        const dim3 grid(grid_for(chunks, h->k1_waves, h->k1_grid_cap)), block(64 * h->k1_waves);
+        const Redirect rd{0, 0, nullptr, nullptr};
+        auto go = [&](auto tag_c) {
+            using TAG = decltype(tag_c);
+            switch (stage) {
+                case 0: hipLaunchKernelGGL(k1_empty_kernel, grid, block, 0, s); break;
+                case 1: hipLaunchKernelGGL((probe_gather_kernel<CD, VEC, TAG, 4, true, 11>), grid, block, 0, s, idx, out, n, 0xFFFFFFF0u, (uint32_t)grid.x, d, rd); break;
+                case 2: hipLaunchKernelGGL((probe_gather_kernel<CD, VEC, TAG, 4, true, 12>), grid, block, 0, s, idx, out, n, 0xFFFFFFF0u, (uint32_t)grid.x, d, rd); break;
+                case 3: hipLaunchKernelGGL((probe_gather_kernel<CD, VEC, TAG, 4, true, 13>), grid, block, 0, s, idx, out, n, 0xFFFFFFF0u, (uint32_t)grid.x, d, rd); break;
+                case 4: hipLaunchKernelGGL((probe_gather_kernel<CD, VEC, TAG, 4, true, 1>), grid, block, 0, s, idx, out, n, 0xFFFFFFF0u, (uint32_t)grid.x, d, rd); break;
+                default: hipLaunchKernelGGL((probe_gather_kernel<CD, VEC, TAG, 4, true, 0>), grid, block, 0, s, idx, out, n, 0xFFFFFFF1u, (uint32_t)grid.x, d, rd); break;
+            }
+        };
+        if (d.tag32) go(uint32_t{}); else go(uint64_t{});
+        return COALA_OK;
+    });
 }
 #endif
 

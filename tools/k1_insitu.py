@@ -44,20 +44,20 @@ torch.cuda.synchronize()
 print(f"# setup {time.time() - t0:.1f}s; rows per minibatch ~{sum(b.numel() for b in batches[400:]) / 220:.0f}", flush=True)
 ctrl = P.SSD_GNN_SSD_Controllers(1, 4096, 1024, 0, 0, dim, True)
 if "--stages" in sys.argv:
-    # where the fixed cost goes: K1's dependency chain cut after each link, launched right behind a real step's cold fill
+    # where the fixed cost goes: K1's dependency chain cut after each link (development switch of the kernel itself: any line size
+    # and tag width), launched right behind a real step's cold fill, on K1's own grid
     import ctypes as C
     from COALA_GNN_Pybind import current_stream
-    os.environ["COALA_K1_TAG64"] = "1"   # the stage kernels read the 64-bit tag layout
     L = C.CDLL(os.environ["COALA_HIP_LIB"])
     L.coala_dev_k1_stage.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
-    cache = P.Isolated_Cache(ctrl := P.SSD_GNN_SSD_Controllers(1, 4096, 1024, 0, 0, dim, True), None, 0, 1, cache_mb, table.device_ptr, num_rows=rows,
-                             sync=False, max_batch=36864)
-    out = torch.empty((36864, dim), dtype=torch.float32, device="cuda")
+    cache = P.Isolated_Cache(ctrl, None, 0, 1, cache_mb, table.device_ptr, num_rows=rows, sync=False, max_batch=max_rows)
+    out = torch.empty((max_rows, dim), dtype=torch.float32, device="cuda")
     for b in batches[:420]:
         cache.read_feature(out.data_ptr(), b.data_ptr(), b.numel())
     torch.cuda.synchronize()
-    names = {0: "empty kernel (launch + drain)", 1: "+ ids", 2: "+ tag sets, ballots", 3: "+ line loads of the hit rows (no stores)", 4: "product kernel without miss bookkeeping", 5: "product kernel (+ a memset of the verdict bytes)", 6: "product kernel without the set_cnt bump", 7: "product kernel, miss atomics only",
-             8: "product kernel, verdict stores only", -1: "empty event bracket"}
+    names = {-1: "empty event bracket", 0: "empty kernel on K1's grid (launch + drain)", 1: "+ ids", 2: "+ tag sets, ballots", 3: "+ line loads of the hit rows (no stores)",
+             4: "product kernel without miss bookkeeping", 5: "product kernel"}
+    print(f"# dim {dim}, tags {cache.geometry().tag_set_bytes} B/set, cache {cache_mb} MiB; separate hipEvent brackets (each contains the ~4.5 us of the empty bracket)")
     for stage in (-1, 0, 1, 2, 3, 4, 5, 4, 5):
         evs = []
         for k, b in enumerate(batches[420:619]):

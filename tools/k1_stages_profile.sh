@@ -6,7 +6,7 @@
 export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-8}
 set -e
 R=${GRAFT_REPO_ROOT:-$PWD}
-OUT=$R/gpurun_out/r02_k1_fixed_cost.txt
+OUT=${OUT:-$R/gpurun_out/r02_k1_fixed_cost.txt}   # shape from the environment of tools/k1_insitu.py (ROWS DIM FANOUT CACHE_MB DEG)
 export TMPDIR=/tmp
 cd /tmp
 python3 $R/coala-gnn_amd/build.py --dev > /dev/null
@@ -19,9 +19,9 @@ python3 - "$f" >> $OUT <<'PY'
 import csv, sys
 for r in csv.DictReader(open(sys.argv[1])):
     n = r["Name"]
-    if "k1_stage_kernel" in n or "probe_gather_kernel" in n or "miss_fill_kernel" in n:
+    if "k1_empty_kernel" in n or "probe_gather_kernel" in n or "miss_fill_kernel" in n:
         short = n.replace("(anonymous namespace)::", "").split("(")[0]
-        print(f"{short[:60]:60s} calls {r['Calls']:>6s}  avg {float(r['AverageNs'])/1e3:8.2f} us  min {float(r['MinNs'])/1e3:8.2f} us  max {float(r['MaxNs'])/1e3:8.2f} us")
+        print(f"{short[:72]:72s} calls {r['Calls']:>6s}  avg {float(r['AverageNs'])/1e3:8.2f} us  min {float(r['MinNs'])/1e3:8.2f} us  max {float(r['MaxNs'])/1e3:8.2f} us")
 PY
 rm -rf $d
 grep -v amdgpu.ids $OUT

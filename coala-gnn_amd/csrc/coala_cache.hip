@@ -180,6 +180,7 @@ struct Geo {
 // (72 k rows) 44.5 us: a launch of this size is one chunk per wave, so its waves overlap each other, not their own chunks, and fewer,
 // fatter waves lose more parallelism than they gain bytes in flight.
 constexpr int k1_np32(int /*cache_dim*/) { return 4; }
+constexpr int64_t kK1SingleMaxChunks = 1 << 20; // launches up to this many chunks (4-8 M rows) get one wave per chunk (SINGLE)
 constexpr int kK1Waves = 2; // waves per block (measured: 2048 x 128 threads beats 1024 x 256 and 256 x 1024 by 3-20 %)
 #ifdef COALA_DEV_KNOBS          // development builds only (build.py --dev -> libcoala_hip_dev.so): launch geometry from the environment
 constexpr int kK1MaxWaves = 4;
@@ -213,7 +214,10 @@ template <typename V> __device__ __forceinline__ void k1_store(V v, V* p) {
 // NOMISS is a development switch (tools/k1_insitu.py --stages: where a launch's time goes; such launches run on a generation nobody
 // consumes): 0 = the product kernel; 1 = no miss bookkeeping; 11 / 12 / 13 = the dependency chain cut short after the id loads /
 // after the tag loads and ballots / after the line loads of the hit rows (no stores).
-template <int CD, int VEC, typename TAG, int NP = 4, bool FULL = false, int NOMISS = 0, bool REDIR = false>
+// SINGLE: the grid has one wave per chunk (every launch up to kK1SingleMaxChunks chunks): no loop and no prefetch state for later
+// chunks, which is what the software pipeline's registers are for -- the short-line kernels drop from 80 to 64 VGPRs or fewer (6 -> 8
+// waves per SIMD), and a launch that is bound by rounds of its waves' dependency chain gets more of them resident.
+template <int CD, int VEC, typename TAG, int NP = 4, bool FULL = false, int NOMISS = 0, bool REDIR = false, bool SINGLE = false>
 __global__ __launch_bounds__(64 * kK1MaxWaves, K1_MIN_WAVES) void probe_gather_kernel(const int64_t* __restrict__ idx, float* __restrict__ out,
                                                                     int64_t n, uint32_t gen, uint32_t n_blocks, CacheDev c, Redirect rd) {
     // Argument order and the explicit block count are deliberate: with kernarg preloading (build.py: -mllvm -amdgpu-kernarg-preload-count=16)
@@ -282,7 +286,7 @@ __global__ __launch_bounds__(64 * kK1MaxWaves, K1_MIN_WAVES) void probe_gather_k
         return;
     }
     Tags tags = load_tags(ids_next);
-    ids_next = load_ids(chunk + n_waves);
+    if (!SINGLE) ids_next = load_ids(chunk + n_waves);
 
     for (; chunk < n_chunks; chunk += n_waves) {
         const int64_t base = chunk * R;
@@ -347,7 +351,8 @@ __global__ __launch_bounds__(64 * kK1MaxWaves, K1_MIN_WAVES) void probe_gather_k
             // (the set's round-robin cursor, isolated_cache.h:203, is advanced by K2: an atomicAdd here cost 1.2 us per launch)
         }
         // ids two chunks ahead (consumed by load_tags in the NEXT iteration: a full row round trip of slack)
-        const Ids ids_next2 = load_ids(chunk + 2 * n_waves);
+        Ids ids_next2;
+        if (!SINGLE) ids_next2 = load_ids(chunk + 2 * n_waves);
 
         // ---- hits: HBM line -> registers -> output row, PASSES row(-pair)s in flight, next chunk's tags requested in between.
         // (Measured alternatives that did not pay: unconditional loads through a dummy address so that the stores get counted
@@ -379,8 +384,10 @@ __global__ __launch_bounds__(64 * kK1MaxWaves, K1_MIN_WAVES) void probe_gather_k
             if (acc == 123456.789f) out[0] = acc;
             return;
         }
-        tags = load_tags(ids_next);
-        ids_next = ids_next2;
+        if (!SINGLE) {
+            tags = load_tags(ids_next);
+            ids_next = ids_next2;
+        }
 #pragma unroll
         for (int p = 0; p < G::PASSES; ++p) {
             const int q = p * G::RPP + sub;
@@ -408,6 +415,7 @@ __global__ __launch_bounds__(64 * kK1MaxWaves, K1_MIN_WAVES) void probe_gather_k
             else if ((badmask >> lane) & 1) w = kLinkBad;
             c.miss_link[base + lane] = w;
         }
+        if (SINGLE) break;
     }
 }
 
@@ -823,6 +831,7 @@ struct coala_cache {
                                           // hits in situ: 2048 blocks -> 22.3 us, 4096 -> 20.7, 8192 -> 20.6; all-hit 36,864 rows: 53.8 / 53.1 / 51.4 us;
                                           // all-hit 123,904 rows: 192.5 / 192.3 / 190.1 / 185.3 us at 2048 / 4096 / 8192 / 16384; 1.08 M x 512 B: 232 -> 227 us
     int k1_waves = kK1Waves;              // K1 waves per block
+    bool k1_single = false;               // one wave per chunk, loop-free K1 (development: COALA_K1_SINGLE=1)
     uint64_t rows_total = 0;              // rows submitted since the last stats reset (hits = rows - misses - rejected)
     uint64_t cum_hit = 0, cum_miss = 0;   // totals folded in whenever coala_cache_stats resets the device counters
     uint64_t prof_hit0 = 0, prof_miss0 = 0; // totals at the last profile reset
@@ -1055,6 +1064,7 @@ int coala_cache_create(const coala_cache_config_t* cfg, coala_cache_t** out) {
         if (const char* e = getenv("COALA_K1_PASSES")) { int v = atoi(e); if (v == 2 || v == 4 || v == 8 || v == 16) h->k1_passes = v; }
         if (const char* e = getenv("COALA_K1_GRID")) { int g = atoi(e); if (g >= 1 && g <= 65535) h->k1_grid_cap = g; }
         if (const char* e = getenv("COALA_K1_WAVES")) { int w = atoi(e); if (w == 1 || w == 2 || w == 4) h->k1_waves = w; }
+        if (const char* e = getenv("COALA_K1_SINGLE")) h->k1_single = atoi(e) != 0;
 #endif
         {
             hipPointerAttribute_t attr;
@@ -1212,8 +1222,14 @@ static int read_feature_impl(coala_cache_t* h, float* out, const int64_t* idx, i
                 using GK = Geo<CD, VEC, NP>;
                 using GR = Geo<CD, VEC, NPR>;
                 const int64_t chunks = redir ? (n + GR::R - 1) / GR::R : (n + GK::R - 1) / GK::R;
-                const dim3 grid(grid_for(chunks, h->k1_waves, h->k1_grid_cap)), block(64 * h->k1_waves);
-                if (redir && full) ps.launch(probe_gather_kernel<CD, VEC, TAG, NPR, true, 0, true>, grid, block, idx, out, n, gen, (uint32_t)grid.x, d, rd);
+                const bool single = h->k1_single && chunks <= kK1SingleMaxChunks;   // one wave per chunk, no loop
+                const dim3 grid(grid_for(chunks, h->k1_waves, single ? (int)((kK1SingleMaxChunks + h->k1_waves - 1) / h->k1_waves) : h->k1_grid_cap)), block(64 * h->k1_waves);
+                if (single) {
+                    if (redir && full) ps.launch(probe_gather_kernel<CD, VEC, TAG, NPR, true, 0, true, true>, grid, block, idx, out, n, gen, (uint32_t)grid.x, d, rd);
+                    else if (redir) ps.launch(probe_gather_kernel<CD, VEC, TAG, NPR, false, 0, true, true>, grid, block, idx, out, n, gen, (uint32_t)grid.x, d, rd);
+                    else if (full) ps.launch(probe_gather_kernel<CD, VEC, TAG, NP, true, 0, false, true>, grid, block, idx, out, n, gen, (uint32_t)grid.x, d, rd);
+                    else ps.launch(probe_gather_kernel<CD, VEC, TAG, NP, false, 0, false, true>, grid, block, idx, out, n, gen, (uint32_t)grid.x, d, rd);
+                } else if (redir && full) ps.launch(probe_gather_kernel<CD, VEC, TAG, NPR, true, 0, true>, grid, block, idx, out, n, gen, (uint32_t)grid.x, d, rd);
                 else if (redir) ps.launch(probe_gather_kernel<CD, VEC, TAG, NPR, false, 0, true>, grid, block, idx, out, n, gen, (uint32_t)grid.x, d, rd);
                 else if (full) ps.launch(probe_gather_kernel<CD, VEC, TAG, NP, true>, grid, block, idx, out, n, gen, (uint32_t)grid.x, d, rd);
                 else ps.launch(probe_gather_kernel<CD, VEC, TAG, NP, false>, grid, block, idx, out, n, gen, (uint32_t)grid.x, d, rd);

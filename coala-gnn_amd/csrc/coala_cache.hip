@@ -420,6 +420,174 @@ __global__ __launch_bounds__(64 * kK1MaxWaves, K1_MIN_WAVES) void probe_gather_k
 }
 
 #ifdef COALA_DEV_KNOBS
+// ---------------------------------------------------------------------------------------------------------- K1, XCD-affine form (development)
+// MEASURED AND NOT ADOPTED (profiles/r03_k1_xcd_affine.txt): 64.4 us against the product's 49.4 us on the configs[3] shape (512-B lines, 16 GiB cache,
+// 315 k rows), 29.2 against 24.1 us at 72 k rows, 20.9 against 17.4 us on the default workload.  Kept in the development build so that the figure
+// can be reproduced (COALA_K1_XCD=1).  The idea: deal the rows to the chip's 8 XCDs by WHERE THEIR LINES LIVE.  The line array (and the tag table) is cut
+// into 8 contiguous parts by set number; the blocks b, b + 8, b + 16 ... -- one XCD under the round-robin placement the dispatcher is observed
+// to use (MI355X_MICROARCH.md, Workgroup dispatch) -- take part b % 8 only.  Every XCD has its own L2 and its own translation cache, so an
+// XCD then touches 1/8 of a 16 GiB line array (1,024 instead of 8,192 pages of 2 MiB) and 1/8 of the tag table.  Placement is a matter of
+// speed only: what a block processes depends on blockIdx, never on the XCD it runs on.
+// No pre-pass and no queues: a wave reads a tile of 64 consecutive ids (every tile is read by one wave of every part: 8 x 8 B per row, from
+// L2 / Infinity Cache after the first reader), keeps the ~8 whose set falls into its part, compacts them into its low lanes with one
+// ds_permute, and runs the chunk machinery of probe_gather_kernel on them.  Row positions are no longer consecutive, which costs nothing: every
+// per-row record of the batch (verdict word, chain link, output row) is indexed by position already.
+// Why it loses: address translation is not what holds the gather back (tools/tlb_thrash_probe: 196,608 random 512-B lines of a 16 GiB buffer read
+// in 16 us whether or not 120 k random host rows were read in between, and no faster when every XCD stays inside one eighth of the buffer), so the
+// partition buys nothing and the wave pays for it: 8 x the id reads, four lane permutes per tile and per tag step, 7 instead of 8 waves per SIMD.
+__device__ __forceinline__ uint32_t lane_push(int dst_lane, uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_permute(dst_lane << 2, (int)v); }
+__device__ __forceinline__ uint32_t lane_pull(int src_lane, uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v); }
+
+template <int CD, int VEC, typename TAG, int NP, bool FULL>
+__global__ __launch_bounds__(128, K1_MIN_WAVES) void probe_gather_xcd_kernel(const int64_t* __restrict__ idx, float* __restrict__ out, int64_t n, uint32_t gen,
+                                                                             uint32_t waves_per_part, uint32_t part_magic, CacheDev c) {
+    using G = Geo<CD, VEC, NP>;
+    using V = typename VecT<VEC>::type;
+    using TG = TagGeo<TAG>;
+    using TV = typename TG::vec;
+    constexpr int R = G::R;
+    static_assert(R <= 32, "per-chunk row masks are 32 bits wide");
+    constexpr int TSTEPS = (R + TG::SPL - 1) / TG::SPL;
+    const int lane = threadIdx.x & 63;
+    const uint32_t part = blockIdx.x & 7u;
+    const int64_t n_tiles = (n + 63) >> 6;
+    const uint32_t nunits = c.dim / VEC;
+    const TAG* __restrict__ keys = reinterpret_cast<const TAG*>(c.keys);
+    const int sub = (G::RPP == 2) ? (lane >> 5) : 0;
+    const int l_in = lane & (G::LPR - 1);
+
+    for (int64_t tile = (int64_t)(blockIdx.x >> 3) * 2 + (threadIdx.x >> 6); tile < n_tiles; tile += waves_per_part) {
+        const int64_t i_l = tile * 64 + lane;
+        const bool valid = i_l < n;
+        const uint64_t id = valid ? (uint64_t)idx[i_l] : 0;
+        const bool ok = valid && id < c.num_rows;
+        const uint32_t set = ok ? (uint32_t)set_of(c, id) : 0u;
+        // part of a row: floor(set * 8 / num_sets) up to rounding (part_magic = floor(2^35 / num_sets): the product never reaches 8); rejected
+        // ids have no set -- they are dealt by position
+        const uint32_t p_l = ok ? __umulhi(set, part_magic) : ((uint32_t)lane & 7u);
+        const bool mine = valid && p_l == part;
+        const uint64_t mm = __ballot(mine);
+        const int cnt = __popcll(mm);
+        if (cnt == 0) continue;
+        // a permutation of the lanes: my rows first, in batch order
+        const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+        const int to = mine ? below : cnt + (lane - below);
+        const uint32_t c_set = lane_push(to, set);
+        const uint32_t c_lo = lane_push(to, (uint32_t)id);
+        uint32_t c_hi = 0u;
+        if (sizeof(TAG) == 8) c_hi = lane_push(to, (uint32_t)(id >> 32));
+        const uint32_t c_meta = lane_push(to, (uint32_t)lane | (ok ? 64u : 0u)); // where the row sits in the tile, and whether its id is in range
+
+        for (int j0 = 0; j0 < cnt; j0 += R) {
+            uint32_t slot[R];
+            uint32_t rpos[R];       // wave-uniform: position of row q in the batch, relative to the tile
+            uint32_t hitmask = 0, missmask = 0, badmask = 0, rowmask = 0;
+            uint32_t my_set = 0, my_pos = 0;
+#pragma unroll
+            for (int t = 0; t < TSTEPS; ++t) {
+                const int q_l = t * TG::SPL + lane / TG::LPS;
+                const int r_l = j0 + q_l;
+                const bool have = (q_l < R) && (r_l < cnt);
+                const int src = have ? r_l : 0;
+                const uint32_t g_set = lane_pull(src, c_set);
+                const uint32_t g_lo = lane_pull(src, c_lo);
+                uint32_t g_hi = 0u;
+                if (sizeof(TAG) == 8) g_hi = lane_pull(src, c_hi);
+                const uint32_t g_meta = lane_pull(src, c_meta);
+                const bool okk = have && (g_meta & 64u);
+                const TAG want = sizeof(TAG) == 8 ? (TAG)(((uint64_t)g_hi << 32) | g_lo) : (TAG)g_lo;
+                TV kk = TV(TG::EMPTY);
+                if (okk) kk = *reinterpret_cast<const TV*>(keys + (uint64_t)g_set * COALA_WAYS + (lane % TG::LPS) * TG::KPL);
+                uint64_t m[TG::KPL];
+#pragma unroll
+                for (int k = 0; k < TG::KPL; ++k) m[k] = __ballot(okk && kk[k] == want);
+                const uint64_t okm = __ballot(okk);
+                const uint64_t vm = __ballot(have);
+#pragma unroll
+                for (int qq = 0; qq < TG::SPL; ++qq) {
+                    const int q = t * TG::SPL + qq;
+                    if (q < R) {
+                        constexpr uint32_t FM = (1u << TG::LPS) - 1u;
+                        uint32_t f[TG::KPL];
+                        uint32_t any = 0;
+#pragma unroll
+                        for (int k = 0; k < TG::KPL; ++k) {
+                            f[k] = (uint32_t)(m[k] >> (TG::LPS * qq)) & FM;
+                            any |= f[k];
+                        }
+                        const bool row_valid = (vm >> (TG::LPS * qq)) & 1;
+                        const bool row_ok = (okm >> (TG::LPS * qq)) & 1;
+                        const uint32_t set_q = (uint32_t)__builtin_amdgcn_readlane((int)g_set, TG::LPS * qq);
+                        const uint32_t pos_q = (uint32_t)__builtin_amdgcn_readlane((int)g_meta, TG::LPS * qq) & 63u;
+                        uint32_t way = 0;
+                        if (any) { // lowest matching way wins (isolated_cache.h:165-172)
+                            const int j = __builtin_ctz(any);
+                            uint32_t kbest = TG::KPL - 1;
+#pragma unroll
+                            for (int k = TG::KPL - 2; k >= 0; --k)
+                                if ((f[k] >> j) & 1) kbest = (uint32_t)k;
+                            way = (uint32_t)(TG::KPL * j) + kbest;
+                            hitmask |= 1u << q;
+                        } else if (row_ok) {
+                            missmask |= 1u << q;
+                        } else if (row_valid) {
+                            badmask |= 1u << q;
+                        }
+                        if (row_valid) rowmask |= 1u << q;
+                        slot[q] = set_q * COALA_WAYS + way;
+                        rpos[q] = pos_q;
+                        if (lane == q) { my_set = set_q; my_pos = pos_q; }
+                    }
+                }
+            }
+            const int64_t tbase = tile * 64;
+            const bool i_miss = lane < R && ((missmask >> lane) & 1);
+            unsigned long long prev = 0;
+            if (i_miss) {
+                const unsigned long long tag = ((unsigned long long)gen << 32) | (unsigned long long)(tbase + my_pos + 1);
+                prev = atomicExch(reinterpret_cast<unsigned long long*>(c.set_head + my_set), tag);
+            }
+            V val[G::PASSES][G::VPL];
+#pragma unroll
+            for (int p = 0; p < G::PASSES; ++p) {
+                const int q = p * G::RPP + sub;
+                const uint32_t s = (G::RPP == 2) ? (sub ? slot[p * G::RPP + (G::RPP - 1)] : slot[p * G::RPP]) : slot[p];
+                const bool h = (hitmask >> q) & 1;
+                const V* src = reinterpret_cast<const V*>(c.lines + (uint64_t)s * CD);
+#pragma unroll
+                for (int v = 0; v < G::VPL; ++v) {
+                    const uint32_t u = v * G::LPR + l_in;
+                    if (h && (FULL || u < nunits)) val[p][v] = k1_load(src + u);
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < G::PASSES; ++p) {
+                const int q = p * G::RPP + sub;
+                const bool h = (hitmask >> q) & 1;
+                const bool bad = (badmask >> q) & 1;
+                const uint32_t rp = (G::RPP == 2) ? (sub ? rpos[p * G::RPP + (G::RPP - 1)] : rpos[p * G::RPP]) : rpos[p];
+                V* dst = reinterpret_cast<V*>(out + (tbase + rp) * (int64_t)c.dim);
+#pragma unroll
+                for (int v = 0; v < G::VPL; ++v) {
+                    const uint32_t u = v * G::LPR + l_in;
+                    if (FULL || u < nunits) {
+                        if (h) k1_store(val[p][v], dst + u);
+                        else if (bad) dst[u] = V(0.0f);
+                    }
+                }
+            }
+            if (lane < R && ((rowmask >> lane) & 1)) {
+                uint32_t w = 0u;
+                if (i_miss) w = kLinkMiss | (((uint32_t)(prev >> 32) == gen) ? (uint32_t)prev : 0u);
+                else if ((badmask >> lane) & 1) w = kLinkBad;
+                c.miss_link[tbase + my_pos] = w;
+            }
+        }
+    }
+}
+#endif // COALA_DEV_KNOBS
+
+#ifdef COALA_DEV_KNOBS
 // Development only (tools/k1_insitu.py --stages): the launch + drain cost of K1's grid with nothing in it.
 __global__ __launch_bounds__(64 * kK1MaxWaves, K1_MIN_WAVES) void k1_empty_kernel() {}
 #endif
@@ -832,6 +1000,7 @@ struct coala_cache {
                                           // all-hit 123,904 rows: 192.5 / 192.3 / 190.1 / 185.3 us at 2048 / 4096 / 8192 / 16384; 1.08 M x 512 B: 232 -> 227 us
     int k1_waves = kK1Waves;              // K1 waves per block
     bool k1_single = false;               // one wave per chunk, loop-free K1 (development: COALA_K1_SINGLE=1)
+    int k1_xcd = 0;                       // XCD-affine K1 (probe_gather_xcd_kernel); development: COALA_K1_XCD = 1 (4 passes) | 2 (8 passes)
     uint64_t rows_total = 0;              // rows submitted since the last stats reset (hits = rows - misses - rejected)
     uint64_t cum_hit = 0, cum_miss = 0;   // totals folded in whenever coala_cache_stats resets the device counters
     uint64_t prof_hit0 = 0, prof_miss0 = 0; // totals at the last profile reset
@@ -1065,6 +1234,7 @@ int coala_cache_create(const coala_cache_config_t* cfg, coala_cache_t** out) {
         if (const char* e = getenv("COALA_K1_GRID")) { int g = atoi(e); if (g >= 1 && g <= 65535) h->k1_grid_cap = g; }
         if (const char* e = getenv("COALA_K1_WAVES")) { int w = atoi(e); if (w == 1 || w == 2 || w == 4) h->k1_waves = w; }
         if (const char* e = getenv("COALA_K1_SINGLE")) h->k1_single = atoi(e) != 0;
+        if (const char* e = getenv("COALA_K1_XCD")) h->k1_xcd = atoi(e);
 #endif
         {
             hipPointerAttribute_t attr;
@@ -1222,6 +1392,22 @@ static int read_feature_impl(coala_cache_t* h, float* out, const int64_t* idx, i
                 using GK = Geo<CD, VEC, NP>;
                 using GR = Geo<CD, VEC, NPR>;
                 const int64_t chunks = redir ? (n + GR::R - 1) / GR::R : (n + GK::R - 1) / GK::R;
+#ifdef COALA_DEV_KNOBS
+                if (h->k1_xcd && !redir && VEC == 4 && d.num_sets > 8) { // XCD-affine form: 8 parts x one wave per tile of 64 ids
+                    const int64_t tiles = (n + 63) / 64;
+                    const uint32_t wpp = (uint32_t)std::min<int64_t>((tiles + 1) & ~1ll, 1 << 17);
+                    const dim3 gx(8u * (wpp / 2)), bx(128);
+                    const uint32_t magic = (uint32_t)((1ull << 35) / d.num_sets);
+                    if (h->k1_xcd == 2 && Geo<CD, VEC, 8>::R <= 32) {
+                        if (full) ps.launch(probe_gather_xcd_kernel<CD, VEC, TAG, 8, true>, gx, bx, idx, out, n, gen, wpp, magic, d);
+                        else ps.launch(probe_gather_xcd_kernel<CD, VEC, TAG, 8, false>, gx, bx, idx, out, n, gen, wpp, magic, d);
+                    } else {
+                        if (full) ps.launch(probe_gather_xcd_kernel<CD, VEC, TAG, 4, true>, gx, bx, idx, out, n, gen, wpp, magic, d);
+                        else ps.launch(probe_gather_xcd_kernel<CD, VEC, TAG, 4, false>, gx, bx, idx, out, n, gen, wpp, magic, d);
+                    }
+                    return;
+                }
+#endif
                 const bool single = h->k1_single && chunks <= kK1SingleMaxChunks;   // one wave per chunk, no loop
                 const dim3 grid(grid_for(chunks, h->k1_waves, single ? (int)((kK1SingleMaxChunks + h->k1_waves - 1) / h->k1_waves) : h->k1_grid_cap)), block(64 * h->k1_waves);
                 if (single) {

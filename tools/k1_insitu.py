@@ -94,13 +94,23 @@ for rep in range(int(os.environ.get("REPS", 2))):
         pre = os.environ.get("COALA_K1_PRE", "")   # experiment: a wide kernel right in front of every K1 (clock / power-state probe)
         scratch = torch.empty(int(pre) << 18, dtype=torch.float32, device="cuda") if pre else None
         t1 = time.perf_counter()
-        for b in batches[420:]:
+        seg_us = []      # K1 per quarter of the timed minibatches: does the figure drift within ONE handle, or only from handle to handle?
+        acc = None
+        for k, b in enumerate(batches[420:]):
             if scratch is not None:
                 scratch.zero_()
             cache.read_feature(out.data_ptr(), b.data_ptr(), b.numel())
+            if os.environ.get("SEGMENTS") and (k + 1) % 50 == 0:
+                torch.cuda.synchronize()
+                q = cache.profile()
+                prev = acc or (0.0, 0)
+                seg_us.append((q.gather_ms - prev[0]) / max(q.gather_launches - prev[1], 1) * 1e3)
+                acc = (q.gather_ms, q.gather_launches)
         torch.cuda.synchronize()
         wall = (time.perf_counter() - t1) / 200 * 1e3
         p = cache.profile()
+        if seg_us:
+            print("   K1 per 50 minibatches: " + " ".join(f"{u:6.2f}" for u in seg_us), flush=True)
         hit, miss, _ = cache.stats()
         alg = p.gather_rows * (8 + tagb) + p.gather_hits * 2 * dim * 4
         us = p.gather_ms / p.gather_launches * 1e3

@@ -582,6 +582,7 @@ def _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, dev
     # algorithmic bytes per launch (DESIGN.md "Kernels"): every probed row reads its int64 id and one 32x8 B tag set;
     # every hit additionally reads a dim*4 line and writes a dim*4 output row  (B_row = 2*dim*4+8+256)
     launches = max(prof.gather_launches, 1)
+    box_copy = _box_copy_gbs(device) if rank == 0 else None   # this box's own streaming-copy rate (untimed; after the timed region)
     tag_set_bytes = int(cache.geometry().tag_set_bytes)   # 128: 32-bit tags (every id < 2^32), 256: the reference's 64-bit tags
     alg_bytes = prof.gather_rows * (8 + tag_set_bytes) + prof.gather_hits * (2 * args.dim * 4)
     k_ms = prof.gather_ms / launches
@@ -590,6 +591,8 @@ def _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, dev
         "bound": "hbm", "kernel": "probe_gather_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": _pmc_traffic(args, world)[0], "traffic_source": _pmc_traffic(args, world)[1],
         "frac_of_measured_copy_6290": round(achieved / HBM_COPY_GBS, 4),
+        # the same binary differs from box to box (profiles/README.md): the box's own copy rate, measured in this process, beside the guide's constant
+        "box_streaming_copy_gbs": box_copy, "frac_of_box_streaming_copy": round(achieved / box_copy, 4) if box_copy else None,
         "avg_launch_us": round(k_ms * 1e3, 2), "timing": "HIP events attached to each launch (hipExtLaunchKernelGGL): kernel begin -> end",
         "separate_event_bracket_would_add_us": round(prof.event_overhead_us, 2),
         "launches": int(prof.gather_launches),
@@ -633,6 +636,7 @@ def _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, dev
             us2 = p2.gather_ms / l2 * 1e3
             ach2 = (b2 / l2) / (us2 * 1e-6) / 1e9 if us2 > 0 else 0.0
             return {"achieved": round(ach2, 1), "frac": round(ach2 / HBM_PEAK_GBS, 4), "frac_of_measured_copy_6290": round(ach2 / HBM_COPY_GBS, 4),
+                    "frac_of_box_streaming_copy": round(ach2 / box_copy, 4) if box_copy else None,
                     "avg_launch_us": round(us2, 2), "launches": int(p2.gather_launches), "rows_per_launch": round(p2.gather_rows / l2, 1),
                     "hit_ratio": round(h2 / max(h2 + m2, 1), 4), "alg_bytes_per_launch": int(b2 / l2), "no_miss_fill_launch_us": round(p2.fill_ms / max(p2.fill_launches, 1) * 1e3, 2)}
         steady = k1_figures(id_sets, args.allhit_launches)
@@ -956,6 +960,28 @@ def run_epoch_leg(args, comm, graph, sampler, table, device, fanout, steps_per_e
                 pass
             del loader, nd
     return out
+
+
+def _box_copy_gbs(device, mib=1024, reps=10):
+    """Read + written GB/s of a plain device-to-device copy of `mib` MiB on THIS box (hipMemcpyAsync D2D, HIP events): the practical ceiling
+    of any read+write kernel here, to put next to the guide's 6.29 TB/s.  A diagnostic: None when it cannot be measured."""
+    try:
+        n = mib << 18
+        src = torch.empty(n, dtype=torch.float32, device=device).fill_(1.0)
+        dst = torch.empty_like(src)
+        for _ in range(2):
+            dst.copy_(src)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            dst.copy_(src)
+        b.record()
+        b.synchronize()
+        gbs = 2.0 * n * 4 * reps / (a.elapsed_time(b) * 1e-3) / 1e9
+        del src, dst
+        return round(gbs, 1)
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def _kernel_source_sha16():

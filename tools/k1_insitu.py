@@ -74,7 +74,11 @@ if "--stages" in sys.argv:
         print(f"stage {stage:2d} {names[stage]:45s} mean {sum(us) / len(us):6.2f} us   median {us[len(us) // 2]:6.2f} us", flush=True)
     sys.exit(0)
 variants = [a for a in sys.argv[1:] if not a.startswith("--")] or ["GRID=2048"]
-out = torch.empty((max_rows, dim), dtype=torch.float32, device="cuda")
+# OUT_BUFFERS=n: the fetches rotate over n output buffers.  bench.py and the loaders get a fresh tensor from the manager for every fetch (two
+# or three blocks of torch's allocator in rotation); with ONE buffer the rows of step s may still sit in the 256 MiB Infinity Cache when step
+# s+1 overwrites them, which flatters the kernel
+outs = [torch.empty((max_rows, dim), dtype=torch.float32, device="cuda") for _ in range(int(os.environ.get("OUT_BUFFERS", 3)))]
+out = outs[0]
 for rep in range(int(os.environ.get("REPS", 2))):
     for v in variants:
         for k in list(os.environ):
@@ -99,7 +103,7 @@ for rep in range(int(os.environ.get("REPS", 2))):
         for k, b in enumerate(batches[420:]):
             if scratch is not None:
                 scratch.zero_()
-            cache.read_feature(out.data_ptr(), b.data_ptr(), b.numel())
+            cache.read_feature(outs[k % len(outs)].data_ptr(), b.data_ptr(), b.numel())
             if os.environ.get("SEGMENTS") and (k + 1) % 50 == 0:
                 torch.cuda.synchronize()
                 q = cache.profile()

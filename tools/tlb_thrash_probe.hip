@@ -47,6 +47,30 @@ __global__ __launch_bounds__(128) void gather(const vu32x4* __restrict__ buf, co
     if (acc == 0x12345678u) out[0] = acc;
 }
 
+// the same gather with the lines written out as consecutive 512-B rows (what K1's hit path does once a row's slot is known)
+template <bool NT>
+__global__ __launch_bounds__(128) void gather_copy(const vu32x4* __restrict__ buf, const uint32_t* __restrict__ line_of, int64_t n_lines, vu32x4* __restrict__ dst) {
+    const int lane = threadIdx.x & 63, sub = lane >> 5, l_in = lane & 31;
+    const int64_t wave = (int64_t)blockIdx.x * 2 + (threadIdx.x >> 6);
+    const int64_t base = wave * 8;
+    if (base >= n_lines) return;
+    vu32x4 v[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int64_t i = base + 2 * p + sub;
+        const uint32_t line = i < n_lines ? line_of[i] : 0;
+        v[p] = __builtin_nontemporal_load(buf + (uint64_t)line * 32 + l_in);
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int64_t i = base + 2 * p + sub;
+        if (i < n_lines) {
+            if (NT) __builtin_nontemporal_store(v[p], dst + i * 32 + l_in);
+            else dst[i * 32 + l_in] = v[p];
+        }
+    }
+}
+
 // bucket k of the list = lines with (line >> shift) == k, at [off[k], off[k+1]); blocks with blockIdx % 8 == k walk bucket k
 __global__ __launch_bounds__(128) void gather_xcd(const vu32x4* __restrict__ buf, const uint32_t* __restrict__ line_of, const uint32_t* __restrict__ off,
                                                   uint32_t* out, uint32_t* xcc_of_block) {
@@ -194,6 +218,22 @@ int main() {
             {"  .. behind the host reads", timed(REPS, th_host, g_xcd_small)},
         };
         for (auto& r : rows) printf("%7lld lines  %-62s: %6.1f / %6.1f us\n", (long long)n, r.name, r.s.mean, r.s.mn);
+        {   // gather + write: one output buffer reused against three in rotation (the Infinity Cache holds 256 MiB)
+            vu32x4* dsts[3];
+            for (auto& d : dsts) CHK(hipMalloc((void**)&d, (size_t)n * 512));
+            auto c1 = [&](int r) { hipLaunchKernelGGL(gather_copy<false>, dim3(grid), dim3(128), 0, 0, buf, d_list[r], n, dsts[0]); };
+            auto c3 = [&](int r) { hipLaunchKernelGGL(gather_copy<false>, dim3(grid), dim3(128), 0, 0, buf, d_list[r], n, dsts[r % 3]); };
+            auto c3nt = [&](int r) { hipLaunchKernelGGL(gather_copy<true>, dim3(grid), dim3(128), 0, 0, buf, d_list[r], n, dsts[r % 3]); };
+            struct { const char* name; Stat s; } rows2[] = {
+                {"gather + write rows, ONE output buffer", timed(REPS, none, c1)},
+                {"gather + write rows, three output buffers in rotation", timed(REPS, none, c3)},
+                {"  .. behind the host reads", timed(REPS, th_host, c3)},
+                {"  .. nontemporal stores", timed(REPS, none, c3nt)},
+                {"gather + write rows, ONE output buffer (again)", timed(REPS, none, c1)},
+            };
+            for (auto& r : rows2) printf("%7lld lines  %-62s: %6.1f / %6.1f us\n", (long long)n, r.name, r.s.mean, r.s.mn);
+            for (auto& d : dsts) CHK(hipFree(d));
+        }
         // does blockIdx % 8 name an XCD?
         hipLaunchKernelGGL(gather_xcd, dim3(grid_x), dim3(128), 0, 0, buf, d_blist[0], d_off[0], out, d_xcc);
         std::vector<uint32_t> xcc(grid_x);

@@ -38,7 +38,14 @@ def build_lib(force=False, verbose=False, dev=False):
     dev=True: libcoala_hip_dev.so with -DCOALA_DEV_KNOBS (launch-geometry knobs from the environment, for tools/k1_insitu.py and
     friends; select it with COALA_HIP_LIB).  The product library reads no tuning knobs."""
     out = DEV_LIB_PATH if dev else LIB_PATH
+    if dev and os.environ.get("COALA_EXTRA_HIPCC_FLAGS"):   # an experimental variant of the development build (-DK1_NT_STORES ...): its own file
+        out = os.path.join(LIB_DIR, "libcoala_hip_var.so")
     if not force and not dev and not needs_build():
+        return out
+    # the development build is rebuilt only when a source is newer than it (or extra flags ask for another variant): the GPU tests ask for it
+    # once per launch shape, and a compile of the whole library is ~50 s
+    if dev and not force and not os.environ.get("COALA_EXTRA_HIPCC_FLAGS") and os.path.exists(out) and \
+            os.path.getmtime(out) >= max(os.path.getmtime(p) for p in sources() + HEADERS + [os.path.abspath(__file__)]):
         return out
     os.makedirs(LIB_DIR, exist_ok=True)
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", os.path.join(_ROOT, "include"),

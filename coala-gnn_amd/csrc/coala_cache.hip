@@ -68,7 +68,6 @@ struct CacheDev {
     uint32_t* miss_link;   // [cap] K1's verdict for every position of the batch, rewritten by every probe (nothing to clear):
                            //       0 = hit, kLinkBad = rejected id, kLinkMiss | (position + 1 of the previously pushed miss of the set; 0 = end)
     unsigned long long* stats; // [kStatBlocks][2] running sums owned by K2's blocks: misses, rejected ids
-    uint32_t* hit_slot;    // [cap] split K1 only: set*32 + way of every position that hit, 0xFFFFFFFF otherwise (rewritten by every probe)
 };
 
 __device__ __forceinline__ uint64_t set_of(const CacheDev& c, uint64_t id) {
@@ -218,8 +217,7 @@ template <typename V> __device__ __forceinline__ void k1_store(V v, V* p) {
 // SINGLE: the grid has one wave per chunk (every launch up to kK1SingleMaxChunks chunks): no loop and no prefetch state for later
 // chunks, which is what the software pipeline's registers are for -- the short-line kernels drop from 80 to 64 VGPRs or fewer (6 -> 8
 // waves per SIMD), and a launch that is bound by rounds of its waves' dependency chain gets more of them resident.
-// SPLIT: the probe half of the two-kernel form (short lines): hits are not copied, their slot goes to c.hit_slot[position] for hit_copy_kernel.
-template <int CD, int VEC, typename TAG, int NP = 4, bool FULL = false, int NOMISS = 0, bool REDIR = false, bool SINGLE = false, bool SPLIT = false>
+template <int CD, int VEC, typename TAG, int NP = 4, bool FULL = false, int NOMISS = 0, bool REDIR = false, bool SINGLE = false>
 __global__ __launch_bounds__(64 * kK1MaxWaves, K1_MIN_WAVES) void probe_gather_kernel(const int64_t* __restrict__ idx, float* __restrict__ out,
                                                                     int64_t n, uint32_t gen, uint32_t n_blocks, CacheDev c, Redirect rd) {
     // Argument order and the explicit block count are deliberate: with kernarg preloading (build.py: -mllvm -amdgpu-kernarg-preload-count=16)
@@ -298,7 +296,6 @@ __global__ __launch_bounds__(64 * kK1MaxWaves, K1_MIN_WAVES) void probe_gather_k
         uint32_t missmask = 0;  // bit q: row q misses (valid, in range, no tag match)
         uint32_t badmask = 0;   // bit q: id outside [0, num_rows)
         uint32_t my_set = 0;    // lane q < R: set of row q
-        uint32_t my_slot = 0;   // lane q < R: slot of row q (SPLIT)
 #pragma unroll
         for (int t = 0; t < TSTEPS; ++t) {
             uint64_t m[TG::KPL];
@@ -338,7 +335,6 @@ __global__ __launch_bounds__(64 * kK1MaxWaves, K1_MIN_WAVES) void probe_gather_k
                     slot[q] = set_q * COALA_WAYS + way;
                     if (REDIR) drow[q] = __builtin_amdgcn_readlane(tags.drow[t], TG::LPS * qq);
                     if (lane == q) my_set = set_q;
-                    if (SPLIT && lane == q) my_slot = slot[q];
                 }
             }
         }
@@ -373,7 +369,7 @@ __global__ __launch_bounds__(64 * kK1MaxWaves, K1_MIN_WAVES) void probe_gather_k
 #pragma unroll
             for (int v = 0; v < G::VPL; ++v) {
                 const uint32_t u = v * G::LPR + l_in;
-                if (!SPLIT && h && (FULL || u < nunits)) val[p][v] = k1_load(src + u);
+                if (h && (FULL || u < nunits)) val[p][v] = k1_load(src + u);
             }
         }
         if (NOMISS == 13) { // (development) + the line loads of the hit rows, nothing stored
@@ -406,12 +402,11 @@ __global__ __launch_bounds__(64 * kK1MaxWaves, K1_MIN_WAVES) void probe_gather_k
             for (int v = 0; v < G::VPL; ++v) {
                 const uint32_t u = v * G::LPR + l_in;
                 if (FULL || u < nunits) {
-                    if (!SPLIT && h) k1_store(val[p][v], dst + u);
+                    if (h) k1_store(val[p][v], dst + u);
                     else if (bad) dst[u] = V(0.0f); // rejected id: zero row (kept inline: hoisting it out costs 12 VGPRs and 10 % speed)
                 }
             }
         }
-        if (SPLIT && lane < R && base + lane < n) c.hit_slot[base + lane] = ((hitmask >> lane) & 1) ? my_slot : 0xFFFFFFFFu;
         // ---- verdict for K2: one word per position, written for EVERY row of the chunk (one 4-byte store per lane q < R), so the
         //      array never needs clearing between batches
         if (NOMISS == 0 && lane < R && base + lane < n) {
@@ -423,253 +418,6 @@ __global__ __launch_bounds__(64 * kK1MaxWaves, K1_MIN_WAVES) void probe_gather_k
         if (SINGLE) break;
     }
 }
-
-// ---------------------------------------------------------------------------------------------------------- K1b (split form, short lines)
-// Copies the rows that hit: line -> output row, DENSELY.  A wave takes a tile of 64 positions, reads their slot words (one coalesced load),
-// packs the hits into its low lanes with one lane permutation and moves them R at a time, the loads of group g+1 issued before the stores
-// of group g.  Against the fused kernel: every row group is full (the fused kernel's 8-row chunk holds ~5 hits at 62 % hits), a wave's
-// life is a stream of line loads and row stores instead of one pass through ids -> tags -> lines -> stores, and the probe in front of it
-// (probe_gather_kernel<..., SPLIT>) is a kernel of its own that touches no line.
-__device__ __forceinline__ uint32_t lane_push(int dst_lane, uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_permute(dst_lane << 2, (int)v); }
-__device__ __forceinline__ uint32_t lane_pull(int src_lane, uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v); }
-
-template <int CD, int VEC, bool FULL, bool REDIR>
-__global__ __launch_bounds__(128, K1_MIN_WAVES) void hit_copy_kernel(float* __restrict__ out, int64_t n, CacheDev c, Redirect rd) {
-    using G = Geo<CD, VEC, 4>;
-    using V = typename VecT<VEC>::type;
-    constexpr int R = G::R;
-    const int lane = threadIdx.x & 63;
-    const int64_t n_tiles = (n + 63) >> 6;
-    const int64_t n_waves = (int64_t)gridDim.x * 2;
-    const uint32_t nunits = c.dim / VEC;
-    const int sub = (G::RPP == 2) ? (lane >> 5) : 0;
-    const int l_in = lane & (G::LPR - 1);
-    for (int64_t tile = (int64_t)blockIdx.x * 2 + (threadIdx.x >> 6); tile < n_tiles; tile += n_waves) {
-        const int64_t pos_l = tile * 64 + lane;
-        const uint32_t s_l = pos_l < n ? c.hit_slot[pos_l] : 0xFFFFFFFFu;
-        const bool hit = s_l != 0xFFFFFFFFu;
-        const uint64_t mm = __ballot(hit);
-        const int cnt = __popcll(mm);
-        if (cnt == 0) continue;
-        int32_t d_l = -1; // REDIR: destination row in rd.out, -1 = row pos_l of the batch's own output
-        if (REDIR && hit && pos_l >= rd.begin && pos_l < rd.end) d_l = (int32_t)(rd.row_map ? rd.row_map[pos_l - rd.begin] : pos_l - rd.begin);
-        // a permutation of the lanes: the hits first, in batch order
-        const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
-        const int to = hit ? below : cnt + (lane - below);
-        const uint32_t c_slot = lane_push(to, s_l);
-        const uint32_t c_lane = lane_push(to, (uint32_t)lane);
-        uint32_t c_drow = 0u;
-        if (REDIR) c_drow = lane_push(to, (uint32_t)d_l);
-        const int64_t tbase = tile * 64;
-
-        auto loads = [&](int g, V (&val)[G::PASSES][G::VPL]) {
-#pragma unroll
-            for (int p = 0; p < G::PASSES; ++p) {
-                const int r = g * R + p * G::RPP + sub;           // (half-)wave-uniform
-                const uint32_t s = lane_pull(r < cnt ? r : 0, c_slot);
-                const V* src = reinterpret_cast<const V*>(c.lines + (uint64_t)s * CD);
-#pragma unroll
-                for (int v = 0; v < G::VPL; ++v) {
-                    const uint32_t u = v * G::LPR + l_in;
-                    if (r < cnt && (FULL || u < nunits)) val[p][v] = k1_load(src + u);
-                }
-            }
-        };
-        auto stores = [&](int g, const V (&val)[G::PASSES][G::VPL]) {
-#pragma unroll
-            for (int p = 0; p < G::PASSES; ++p) {
-                const int r = g * R + p * G::RPP + sub;
-                const uint32_t pl = lane_pull(r < cnt ? r : 0, c_lane);
-                V* dst = reinterpret_cast<V*>(out + (tbase + pl) * (int64_t)c.dim);
-                if (REDIR) {
-                    const int32_t dr = (int32_t)lane_pull(r < cnt ? r : 0, c_drow);
-                    if (dr >= 0) dst = reinterpret_cast<V*>(rd.out + (int64_t)dr * (int64_t)c.dim);
-                }
-#pragma unroll
-                for (int v = 0; v < G::VPL; ++v) {
-                    const uint32_t u = v * G::LPR + l_in;
-                    if (r < cnt && (FULL || u < nunits)) k1_store(val[p][v], dst + u);
-                }
-            }
-        };
-        const int ng = (cnt + R - 1) / R;
-        V va[G::PASSES][G::VPL], vb[G::PASSES][G::VPL];
-        loads(0, va);
-        for (int g = 0;;) {
-            if (g + 1 < ng) loads(g + 1, vb);
-            stores(g, va);
-            if (++g >= ng) break;
-            if (g + 1 < ng) loads(g + 1, va);
-            stores(g, vb);
-            if (++g >= ng) break;
-        }
-    }
-}
-
-#ifdef COALA_DEV_KNOBS
-// ---------------------------------------------------------------------------------------------------------- K1, XCD-affine form (development)
-// MEASURED AND NOT ADOPTED (profiles/r03_k1_xcd_affine.txt): 64.4 us against the product's 49.4 us on the configs[3] shape (512-B lines, 16 GiB cache,
-// 315 k rows), 29.2 against 24.1 us at 72 k rows, 20.9 against 17.4 us on the default workload.  Kept in the development build so that the figure
-// can be reproduced (COALA_K1_XCD=1).  The idea: deal the rows to the chip's 8 XCDs by WHERE THEIR LINES LIVE.  The line array (and the tag table) is cut
-// into 8 contiguous parts by set number; the blocks b, b + 8, b + 16 ... -- one XCD under the round-robin placement the dispatcher is observed
-// to use (MI355X_MICROARCH.md, Workgroup dispatch) -- take part b % 8 only.  Every XCD has its own L2 and its own translation cache, so an
-// XCD then touches 1/8 of a 16 GiB line array (1,024 instead of 8,192 pages of 2 MiB) and 1/8 of the tag table.  Placement is a matter of
-// speed only: what a block processes depends on blockIdx, never on the XCD it runs on.
-// No pre-pass and no queues: a wave reads a tile of 64 consecutive ids (every tile is read by one wave of every part: 8 x 8 B per row, from
-// L2 / Infinity Cache after the first reader), keeps the ~8 whose set falls into its part, compacts them into its low lanes with one
-// ds_permute, and runs the chunk machinery of probe_gather_kernel on them.  Row positions are no longer consecutive, which costs nothing: every
-// per-row record of the batch (verdict word, chain link, output row) is indexed by position already.
-// Why it loses: address translation is not what holds the gather back (tools/tlb_thrash_probe: 196,608 random 512-B lines of a 16 GiB buffer read
-// in 16 us whether or not 120 k random host rows were read in between, and no faster when every XCD stays inside one eighth of the buffer), so the
-// partition buys nothing and the wave pays for it: 8 x the id reads, four lane permutes per tile and per tag step, 7 instead of 8 waves per SIMD.
-template <int CD, int VEC, typename TAG, int NP, bool FULL>
-__global__ __launch_bounds__(128, K1_MIN_WAVES) void probe_gather_xcd_kernel(const int64_t* __restrict__ idx, float* __restrict__ out, int64_t n, uint32_t gen,
-                                                                             uint32_t waves_per_part, uint32_t part_magic, CacheDev c) {
-    using G = Geo<CD, VEC, NP>;
-    using V = typename VecT<VEC>::type;
-    using TG = TagGeo<TAG>;
-    using TV = typename TG::vec;
-    constexpr int R = G::R;
-    static_assert(R <= 32, "per-chunk row masks are 32 bits wide");
-    constexpr int TSTEPS = (R + TG::SPL - 1) / TG::SPL;
-    const int lane = threadIdx.x & 63;
-    const uint32_t part = blockIdx.x & 7u;
-    const int64_t n_tiles = (n + 63) >> 6;
-    const uint32_t nunits = c.dim / VEC;
-    const TAG* __restrict__ keys = reinterpret_cast<const TAG*>(c.keys);
-    const int sub = (G::RPP == 2) ? (lane >> 5) : 0;
-    const int l_in = lane & (G::LPR - 1);
-
-    for (int64_t tile = (int64_t)(blockIdx.x >> 3) * 2 + (threadIdx.x >> 6); tile < n_tiles; tile += waves_per_part) {
-        const int64_t i_l = tile * 64 + lane;
-        const bool valid = i_l < n;
-        const uint64_t id = valid ? (uint64_t)idx[i_l] : 0;
-        const bool ok = valid && id < c.num_rows;
-        const uint32_t set = ok ? (uint32_t)set_of(c, id) : 0u;
-        // part of a row: floor(set * 8 / num_sets) up to rounding (part_magic = floor(2^35 / num_sets): the product never reaches 8); rejected
-        // ids have no set -- they are dealt by position
-        const uint32_t p_l = ok ? __umulhi(set, part_magic) : ((uint32_t)lane & 7u);
-        const bool mine = valid && p_l == part;
-        const uint64_t mm = __ballot(mine);
-        const int cnt = __popcll(mm);
-        if (cnt == 0) continue;
-        // a permutation of the lanes: my rows first, in batch order
-        const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
-        const int to = mine ? below : cnt + (lane - below);
-        const uint32_t c_set = lane_push(to, set);
-        const uint32_t c_lo = lane_push(to, (uint32_t)id);
-        uint32_t c_hi = 0u;
-        if (sizeof(TAG) == 8) c_hi = lane_push(to, (uint32_t)(id >> 32));
-        const uint32_t c_meta = lane_push(to, (uint32_t)lane | (ok ? 64u : 0u)); // where the row sits in the tile, and whether its id is in range
-
-        for (int j0 = 0; j0 < cnt; j0 += R) {
-            uint32_t slot[R];
-            uint32_t rpos[R];       // wave-uniform: position of row q in the batch, relative to the tile
-            uint32_t hitmask = 0, missmask = 0, badmask = 0, rowmask = 0;
-            uint32_t my_set = 0, my_pos = 0;
-#pragma unroll
-            for (int t = 0; t < TSTEPS; ++t) {
-                const int q_l = t * TG::SPL + lane / TG::LPS;
-                const int r_l = j0 + q_l;
-                const bool have = (q_l < R) && (r_l < cnt);
-                const int src = have ? r_l : 0;
-                const uint32_t g_set = lane_pull(src, c_set);
-                const uint32_t g_lo = lane_pull(src, c_lo);
-                uint32_t g_hi = 0u;
-                if (sizeof(TAG) == 8) g_hi = lane_pull(src, c_hi);
-                const uint32_t g_meta = lane_pull(src, c_meta);
-                const bool okk = have && (g_meta & 64u);
-                const TAG want = sizeof(TAG) == 8 ? (TAG)(((uint64_t)g_hi << 32) | g_lo) : (TAG)g_lo;
-                TV kk = TV(TG::EMPTY);
-                if (okk) kk = *reinterpret_cast<const TV*>(keys + (uint64_t)g_set * COALA_WAYS + (lane % TG::LPS) * TG::KPL);
-                uint64_t m[TG::KPL];
-#pragma unroll
-                for (int k = 0; k < TG::KPL; ++k) m[k] = __ballot(okk && kk[k] == want);
-                const uint64_t okm = __ballot(okk);
-                const uint64_t vm = __ballot(have);
-#pragma unroll
-                for (int qq = 0; qq < TG::SPL; ++qq) {
-                    const int q = t * TG::SPL + qq;
-                    if (q < R) {
-                        constexpr uint32_t FM = (1u << TG::LPS) - 1u;
-                        uint32_t f[TG::KPL];
-                        uint32_t any = 0;
-#pragma unroll
-                        for (int k = 0; k < TG::KPL; ++k) {
-                            f[k] = (uint32_t)(m[k] >> (TG::LPS * qq)) & FM;
-                            any |= f[k];
-                        }
-                        const bool row_valid = (vm >> (TG::LPS * qq)) & 1;
-                        const bool row_ok = (okm >> (TG::LPS * qq)) & 1;
-                        const uint32_t set_q = (uint32_t)__builtin_amdgcn_readlane((int)g_set, TG::LPS * qq);
-                        const uint32_t pos_q = (uint32_t)__builtin_amdgcn_readlane((int)g_meta, TG::LPS * qq) & 63u;
-                        uint32_t way = 0;
-                        if (any) { // lowest matching way wins (isolated_cache.h:165-172)
-                            const int j = __builtin_ctz(any);
-                            uint32_t kbest = TG::KPL - 1;
-#pragma unroll
-                            for (int k = TG::KPL - 2; k >= 0; --k)
-                                if ((f[k] >> j) & 1) kbest = (uint32_t)k;
-                            way = (uint32_t)(TG::KPL * j) + kbest;
-                            hitmask |= 1u << q;
-                        } else if (row_ok) {
-                            missmask |= 1u << q;
-                        } else if (row_valid) {
-                            badmask |= 1u << q;
-                        }
-                        if (row_valid) rowmask |= 1u << q;
-                        slot[q] = set_q * COALA_WAYS + way;
-                        rpos[q] = pos_q;
-                        if (lane == q) { my_set = set_q; my_pos = pos_q; }
-                    }
-                }
-            }
-            const int64_t tbase = tile * 64;
-            const bool i_miss = lane < R && ((missmask >> lane) & 1);
-            unsigned long long prev = 0;
-            if (i_miss) {
-                const unsigned long long tag = ((unsigned long long)gen << 32) | (unsigned long long)(tbase + my_pos + 1);
-                prev = atomicExch(reinterpret_cast<unsigned long long*>(c.set_head + my_set), tag);
-            }
-            V val[G::PASSES][G::VPL];
-#pragma unroll
-            for (int p = 0; p < G::PASSES; ++p) {
-                const int q = p * G::RPP + sub;
-                const uint32_t s = (G::RPP == 2) ? (sub ? slot[p * G::RPP + (G::RPP - 1)] : slot[p * G::RPP]) : slot[p];
-                const bool h = (hitmask >> q) & 1;
-                const V* src = reinterpret_cast<const V*>(c.lines + (uint64_t)s * CD);
-#pragma unroll
-                for (int v = 0; v < G::VPL; ++v) {
-                    const uint32_t u = v * G::LPR + l_in;
-                    if (h && (FULL || u < nunits)) val[p][v] = k1_load(src + u);
-                }
-            }
-#pragma unroll
-            for (int p = 0; p < G::PASSES; ++p) {
-                const int q = p * G::RPP + sub;
-                const bool h = (hitmask >> q) & 1;
-                const bool bad = (badmask >> q) & 1;
-                const uint32_t rp = (G::RPP == 2) ? (sub ? rpos[p * G::RPP + (G::RPP - 1)] : rpos[p * G::RPP]) : rpos[p];
-                V* dst = reinterpret_cast<V*>(out + (tbase + rp) * (int64_t)c.dim);
-#pragma unroll
-                for (int v = 0; v < G::VPL; ++v) {
-                    const uint32_t u = v * G::LPR + l_in;
-                    if (FULL || u < nunits) {
-                        if (h) k1_store(val[p][v], dst + u);
-                        else if (bad) dst[u] = V(0.0f);
-                    }
-                }
-            }
-            if (lane < R && ((rowmask >> lane) & 1)) {
-                uint32_t w = 0u;
-                if (i_miss) w = kLinkMiss | (((uint32_t)(prev >> 32) == gen) ? (uint32_t)prev : 0u);
-                else if ((badmask >> lane) & 1) w = kLinkBad;
-                c.miss_link[tbase + my_pos] = w;
-            }
-        }
-    }
-}
-#endif // COALA_DEV_KNOBS
 
 #ifdef COALA_DEV_KNOBS
 // Development only (tools/k1_insitu.py --stages): the launch + drain cost of K1's grid with nothing in it.
@@ -1084,8 +832,6 @@ struct coala_cache {
                                           // all-hit 123,904 rows: 192.5 / 192.3 / 190.1 / 185.3 us at 2048 / 4096 / 8192 / 16384; 1.08 M x 512 B: 232 -> 227 us
     int k1_waves = kK1Waves;              // K1 waves per block
     bool k1_single = false;               // one wave per chunk, loop-free K1 (development: COALA_K1_SINGLE=1)
-    int k1_split = 0;                     // two-kernel K1 (probe, then dense hit copy); development: COALA_K1_SPLIT = rows per probe chunk / 8 (1, 2, 4)
-    int k1_xcd = 0;                       // XCD-affine K1 (probe_gather_xcd_kernel); development: COALA_K1_XCD = 1 (4 passes) | 2 (8 passes)
     uint64_t rows_total = 0;              // rows submitted since the last stats reset (hits = rows - misses - rejected)
     uint64_t cum_hit = 0, cum_miss = 0;   // totals folded in whenever coala_cache_stats resets the device counters
     uint64_t prof_hit0 = 0, prof_miss0 = 0; // totals at the last profile reset
@@ -1123,9 +869,6 @@ int ensure_scratch(coala_cache* h, uint64_t n, hipStream_t s) {
     if (h->d.miss_link) HIPCHK(hipFree(h->d.miss_link));
     h->d.miss_link = nullptr;
     HIPCHK(hipMalloc((void**)&h->d.miss_link, cap * sizeof(uint32_t))); // written by every probe before any fill reads it
-    if (h->d.hit_slot) HIPCHK(hipFree(h->d.hit_slot));
-    h->d.hit_slot = nullptr;
-    HIPCHK(hipMalloc((void**)&h->d.hit_slot, cap * sizeof(uint32_t)));  // written by every split probe before its copy kernel reads it
     h->cap = cap;
     return COALA_OK;
 }
@@ -1170,17 +913,6 @@ struct ProfScope {
     template <typename K, typename... Args>
     void launch(K kernel, dim3 grid, dim3 block, Args... args) {
         if (on) hipExtLaunchKernelGGL(kernel, grid, block, 0, s, a, b, 0, args...);
-        else hipLaunchKernelGGL(kernel, grid, block, 0, s, args...);
-    }
-    // a pair of launches timed as one: begin of the first -> end of the second
-    template <typename K, typename... Args>
-    void launch_first(K kernel, dim3 grid, dim3 block, Args... args) {
-        if (on) hipExtLaunchKernelGGL(kernel, grid, block, 0, s, a, nullptr, 0, args...);
-        else hipLaunchKernelGGL(kernel, grid, block, 0, s, args...);
-    }
-    template <typename K, typename... Args>
-    void launch_last(K kernel, dim3 grid, dim3 block, Args... args) {
-        if (on) hipExtLaunchKernelGGL(kernel, grid, block, 0, s, nullptr, b, 0, args...);
         else hipLaunchKernelGGL(kernel, grid, block, 0, s, args...);
     }
     ~ProfScope() {
@@ -1333,8 +1065,6 @@ int coala_cache_create(const coala_cache_config_t* cfg, coala_cache_t** out) {
         if (const char* e = getenv("COALA_K1_GRID")) { int g = atoi(e); if (g >= 1 && g <= 65535) h->k1_grid_cap = g; }
         if (const char* e = getenv("COALA_K1_WAVES")) { int w = atoi(e); if (w == 1 || w == 2 || w == 4) h->k1_waves = w; }
         if (const char* e = getenv("COALA_K1_SINGLE")) h->k1_single = atoi(e) != 0;
-        if (const char* e = getenv("COALA_K1_XCD")) h->k1_xcd = atoi(e);
-        if (const char* e = getenv("COALA_K1_SPLIT")) h->k1_split = atoi(e);
 #endif
         {
             hipPointerAttribute_t attr;
@@ -1375,7 +1105,7 @@ int coala_cache_destroy(coala_cache_t* h) {
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
     CacheDev& d = h->d;
     void* ptrs[] = {d.keys, d.set_cnt, d.color_meta, d.set_head, d.stats, d.lines, d.color_counters,
-                    h->node_color_dev, d.miss_link, d.hit_slot,
+                    h->node_color_dev, d.miss_link,
                     h->wave_counts, h->route_bases};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -1492,45 +1222,6 @@ static int read_feature_impl(coala_cache_t* h, float* out, const int64_t* idx, i
                 using GK = Geo<CD, VEC, NP>;
                 using GR = Geo<CD, VEC, NPR>;
                 const int64_t chunks = redir ? (n + GR::R - 1) / GR::R : (n + GK::R - 1) / GK::R;
-                if constexpr (VEC == 4 && CD <= 256) {
-                    if (h->k1_split) { // two kernels: the probe (no line touched), then the dense copy of the rows that hit
-                        auto split = [&](auto np_s) {
-                            constexpr int NPS = decltype(np_s)::value;
-                            using GS = Geo<CD, VEC, NPS>;
-                            const int64_t ch = (n + GS::R - 1) / GS::R;
-                            const dim3 g1(grid_for(ch, 2, 1 << 20)), b1(128);
-                            if (redir && full) ps.launch_first(probe_gather_kernel<CD, VEC, TAG, NPS, true, 0, true, true, true>, g1, b1, idx, out, n, gen, (uint32_t)g1.x, d, rd);
-                            else if (redir) ps.launch_first(probe_gather_kernel<CD, VEC, TAG, NPS, false, 0, true, true, true>, g1, b1, idx, out, n, gen, (uint32_t)g1.x, d, rd);
-                            else if (full) ps.launch_first(probe_gather_kernel<CD, VEC, TAG, NPS, true, 0, false, true, true>, g1, b1, idx, out, n, gen, (uint32_t)g1.x, d, rd);
-                            else ps.launch_first(probe_gather_kernel<CD, VEC, TAG, NPS, false, 0, false, true, true>, g1, b1, idx, out, n, gen, (uint32_t)g1.x, d, rd);
-                        };
-                        if (h->k1_split >= 4 && !redir) split(std::integral_constant<int, (Geo<CD, VEC, 16>::R <= 32 ? 16 : 8)>{}); // (with a destination per row 32-row chunks spill)
-                        else if (h->k1_split >= 2) split(std::integral_constant<int, 8>{});
-                        else split(std::integral_constant<int, 4>{});
-                        const dim3 g2(grid_for((n + 63) / 64, 2, h->k1_grid_cap)), b2(128);
-                        if (redir && full) ps.launch_last(hit_copy_kernel<CD, VEC, true, true>, g2, b2, out, n, d, rd);
-                        else if (redir) ps.launch_last(hit_copy_kernel<CD, VEC, false, true>, g2, b2, out, n, d, rd);
-                        else if (full) ps.launch_last(hit_copy_kernel<CD, VEC, true, false>, g2, b2, out, n, d, rd);
-                        else ps.launch_last(hit_copy_kernel<CD, VEC, false, false>, g2, b2, out, n, d, rd);
-                        return;
-                    }
-                }
-#ifdef COALA_DEV_KNOBS
-                if (h->k1_xcd && !redir && VEC == 4 && d.num_sets > 8) { // XCD-affine form: 8 parts x one wave per tile of 64 ids
-                    const int64_t tiles = (n + 63) / 64;
-                    const uint32_t wpp = (uint32_t)std::min<int64_t>((tiles + 1) & ~1ll, 1 << 17);
-                    const dim3 gx(8u * (wpp / 2)), bx(128);
-                    const uint32_t magic = (uint32_t)((1ull << 35) / d.num_sets);
-                    if (h->k1_xcd == 2 && Geo<CD, VEC, 8>::R <= 32) {
-                        if (full) ps.launch(probe_gather_xcd_kernel<CD, VEC, TAG, 8, true>, gx, bx, idx, out, n, gen, wpp, magic, d);
-                        else ps.launch(probe_gather_xcd_kernel<CD, VEC, TAG, 8, false>, gx, bx, idx, out, n, gen, wpp, magic, d);
-                    } else {
-                        if (full) ps.launch(probe_gather_xcd_kernel<CD, VEC, TAG, 4, true>, gx, bx, idx, out, n, gen, wpp, magic, d);
-                        else ps.launch(probe_gather_xcd_kernel<CD, VEC, TAG, 4, false>, gx, bx, idx, out, n, gen, wpp, magic, d);
-                    }
-                    return;
-                }
-#endif
                 const bool single = h->k1_single && chunks <= kK1SingleMaxChunks;   // one wave per chunk, no loop
                 const dim3 grid(grid_for(chunks, h->k1_waves, single ? (int)((kK1SingleMaxChunks + h->k1_waves - 1) / h->k1_waves) : h->k1_grid_cap)), block(64 * h->k1_waves);
                 if (single) {

@@ -21,11 +21,7 @@ KNOBS = {2: {"COALA_K2_TILE_ROWS": "0"}, 3: {"COALA_K2_TILE_ROWS": "16", "COALA_
          4: {"COALA_K2_TILE_ROWS": "64", "COALA_K2_GRID": "1", "COALA_K1_GRID": "5"}, 5: {"COALA_K1_WAVES": "4", "COALA_K1_PASSES": "2"},
          6: {"COALA_K2_SPARSE": "64"}, 7: {"COALA_K2_SPARSE": "0"}, 8: {"COALA_K2_SPARSE": "5", "COALA_K2_TILE_ROWS": "32", "COALA_K2_GRID": "2"},
          # rows in flight per wave of the probe+gather kernel: 16 passes (16 / 32 rows per chunk on short lines), 8 passes on a tiny grid
-         9: {"COALA_K1_PASSES": "16"}, 10: {"COALA_K1_PASSES": "8", "COALA_K1_GRID": "3"},
-         # the XCD-affine probe+gather kernel of the development build (rows dealt to 8 parts of the line array)
-         11: {"COALA_K1_XCD": "1"},
-         # the two-kernel form of the probe + gather on short lines (probe, then dense copy of the hits), 8 and 32 rows per probe chunk
-         12: {"COALA_K1_SPLIT": "1"}, 13: {"COALA_K1_SPLIT": "4", "COALA_K1_GRID": "7"}}
+         9: {"COALA_K1_PASSES": "16"}, 10: {"COALA_K1_PASSES": "8", "COALA_K1_GRID": "3"}}
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])

@@ -14,7 +14,8 @@ for dim, n, rows in ((1024, 123904, 2_000_000), (256, 262144, 4_000_000), (128, 
     ctrl = P.SSD_GNN_SSD_Controllers(1, 4096, 1024, 0, 0, dim, True)
     perm = torch.randperm(rows, device="cuda")
     warm = perm[:n].contiguous()
-    out = torch.empty((n, dim), dtype=torch.float32, device="cuda")
+    outs = [torch.empty((n, dim), dtype=torch.float32, device="cuda") for _ in range(3)]   # in rotation: a reused buffer is partly still in the Infinity Cache when it is overwritten
+    out = outs[0]
     for hit in (90, 100):
         cache = P.Isolated_Cache(ctrl, None, 0, 1, 4096, table.data_ptr(), num_rows=rows, profile=True, sync=False, max_batch=n)
         cache.read_feature(out.data_ptr(), warm.data_ptr(), n)
@@ -25,7 +26,7 @@ for dim, n, rows in ((1024, 123904, 2_000_000), (256, 262144, 4_000_000), (128, 
             ids = torch.cat([warm[:k], cold[: n - k]])[torch.randperm(n, device="cuda")].contiguous()
             torch.cuda.synchronize()
             cache.profile(reset=True)
-            cache.read_feature(out.data_ptr(), ids.data_ptr(), n)
+            cache.read_feature(outs[(rep + 1) % 3].data_ptr(), ids.data_ptr(), n)
             torch.cuda.synchronize()
             p = cache.profile()
             us.append(round(p.gather_ms / max(p.gather_launches, 1) * 1e3, 1))
@@ -33,4 +34,4 @@ for dim, n, rows in ((1024, 123904, 2_000_000), (256, 262144, 4_000_000), (128, 
         alg = n * (8 + cache.geometry().tag_set_bytes) + k * 2 * dim * 4
         print(f"{tag:28s} dim {dim:5d} n={n:8d} hit {hit:3d} %: K1 {t:8.2f} us = {alg / t / 1e3 / 80:5.1f} % of 8 TB/s   all: {us}", flush=True)
         cache.close()
-    del table, out
+    del table, out, outs

@@ -19,7 +19,8 @@ for dim, n, rows in SHAPES:
     ctrl = P.SSD_GNN_SSD_Controllers(1, 4096, 1024, 0, 0, dim, True)
     perm = torch.randperm(rows, device="cuda")
     warm = perm[:n].contiguous()
-    out = torch.empty((n, dim), dtype=torch.float32, device="cuda")
+    outs = [torch.empty((n, dim), dtype=torch.float32, device="cuda") for _ in range(3)]   # in rotation: a reused buffer is partly still in the Infinity Cache when it is overwritten
+    out = outs[0]
     for hit in HITS:   # 0.25 / 0.5 / 0.75 / 0.9, plus the default workload (0.32) and the two ends
         cache = P.Isolated_Cache(ctrl, None, 0, 1, int(os.environ.get('CACHE_MB', 4096)), table.data_ptr(), num_rows=rows, profile=True, sync=False, max_batch=n, tag64=TAG64)
         cache_tag_bytes = cache.geometry().tag_set_bytes
@@ -34,7 +35,7 @@ for dim, n, rows in SHAPES:
             ids = torch.cat([warm[:k], cold[: n - k]])[torch.randperm(n, device="cuda")].contiguous()
             torch.cuda.synchronize()
             cache.profile(reset=True)
-            cache.read_feature(out.data_ptr(), ids.data_ptr(), n)
+            cache.read_feature(outs[(rep + 1) % 3].data_ptr(), ids.data_ptr(), n)
             torch.cuda.synchronize()
             p = cache.profile()
             us.append(p.gather_ms / max(p.gather_launches, 1) * 1e3)

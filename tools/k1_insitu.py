@@ -97,12 +97,21 @@ for rep in range(int(os.environ.get("REPS", 2))):
         cache.profile(reset=True)
         pre = os.environ.get("COALA_K1_PRE", "")   # experiment: a wide kernel right in front of every K1 (clock / power-state probe)
         scratch = torch.empty(int(pre) << 18, dtype=torch.float32, device="cuda") if pre else None
+        # BUSY=n: n compute-bound kernels (bf16 2048^3 matrix products, ~15 us each, 24 MB of operands) between the PCIe-bound fill of one step and the
+        # K1 of the next: does K1 start on a chip that has clocked down during ~1 ms of near-idle?  (events attached to K1 itself: the products are not timed)
+        busy = int(os.environ.get("COALA_K1_BUSY", "0"))
+        if busy:
+            mm_a = torch.randn((2048, 2048), dtype=torch.bfloat16, device="cuda")
+            mm_b = torch.randn((2048, 2048), dtype=torch.bfloat16, device="cuda")
+            mm_c = torch.empty((2048, 2048), dtype=torch.bfloat16, device="cuda")
         t1 = time.perf_counter()
         seg_us = []      # K1 per quarter of the timed minibatches: does the figure drift within ONE handle, or only from handle to handle?
         acc = None
         for k, b in enumerate(batches[420:]):
             if scratch is not None:
                 scratch.zero_()
+            for _ in range(busy):
+                torch.mm(mm_a, mm_b, out=mm_c)
             cache.read_feature(outs[k % len(outs)].data_ptr(), b.data_ptr(), b.numel())
             if os.environ.get("SEGMENTS") and (k + 1) % 50 == 0:
                 torch.cuda.synchronize()

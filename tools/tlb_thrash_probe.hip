@@ -119,6 +119,23 @@ __global__ __launch_bounds__(256) void thrash(const vu32x4* __restrict__ buf, co
 
 __global__ void empty_kernel() {}
 
+// latency: ONE wave walks a chain of random 512-B lines (the first dword of a line names the next one); ns per dependent hop
+__global__ void chain_init(vu32x4* buf, const uint32_t* seq, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) buf[(uint64_t)seq[i] * 32].x = seq[(i + 1) % n];
+}
+__global__ void chain_walk(const vu32x4* __restrict__ buf, uint32_t start, int hops, uint32_t* out) {
+    const int lane = threadIdx.x & 31;
+    uint32_t line = start, acc = 0;
+    for (int h = 0; h < hops; ++h) {
+        const vu32x4 v = __builtin_nontemporal_load(buf + (uint64_t)line * 32 + lane);
+        acc += v.y;
+        line = (uint32_t)__builtin_amdgcn_readfirstlane((int)v.x);
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+    if (threadIdx.x == 0) out[1] = line;
+}
+
 static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
 static uint64_t rnd() {
     uint64_t z = (rng_state += 0x9E3779B97F4A7C15ull);
@@ -174,6 +191,23 @@ int main() {
     {
         auto s = timed(REPS, [](int) {}, [&](int) { hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, 0); });
         printf("empty kernel in the bracket                                   : %6.1f / %6.1f us\n", s.mean, s.mn);
+    }
+    {   // dependent-load latency on this box, idle chip: what a latency-bound kernel (K1 on short lines) is made of
+        const int n_chain = 65536;
+        std::vector<uint32_t> seq(n_chain);
+        for (auto& x : seq) x = (uint32_t)(rnd() % n_total);
+        uint32_t* d_seq;
+        CHK(hipMalloc((void**)&d_seq, n_chain * 4));
+        CHK(hipMemcpy(d_seq, seq.data(), n_chain * 4, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(chain_init, dim3(n_chain / 256), dim3(256), 0, 0, buf, d_seq, n_chain);
+        CHK(hipDeviceSynchronize());
+        for (int pass = 0; pass < 2; ++pass) {
+            // pass 0: the chain's lines pushed out of L2 / Infinity Cache first (600 MB of other reads); pass 1: walked again right away (8 MB: cache-resident)
+            if (pass == 0) for (int r = 0; r < REPS; ++r) hipLaunchKernelGGL(thrash, dim3(2048), dim3(256), 0, 0, buf2, d_thrash[r], n_thrash, out);
+            auto s = timed(1, [](int) {}, [&](int) { hipLaunchKernelGGL(chain_walk, dim3(1), dim3(64), 0, 0, buf, seq[0], n_chain, out); });
+            printf("dependent chain of %d random 512-B lines of the 16 GiB buffer, one wave, %s: %6.1f ns per hop\n", n_chain, pass ? "walked again (cache-resident)" : "from HBM                     ", (s.mn - 6.0) * 1e3 / n_chain);
+        }
+        CHK(hipFree(d_seq));
     }
     for (int64_t n : {(int64_t)43008, (int64_t)196608}) {
         uint32_t *d_list[REPS], *d_blist[REPS], *d_off[REPS], *d_xcc;

@@ -68,7 +68,6 @@ struct CacheDev {
     uint32_t* miss_link;   // [cap] K1's verdict for every position of the batch, rewritten by every probe (nothing to clear):
                            //       0 = hit, kLinkBad = rejected id, kLinkMiss | (position + 1 of the previously pushed miss of the set; 0 = end)
     unsigned long long* stats; // [kStatBlocks][2] running sums owned by K2's blocks: misses, rejected ids
-    uint32_t k1_pf_waves;  // K1's cross-wave prefetch distance in waves (a multiple of 16; 0 = off)
 };
 
 __device__ __forceinline__ uint64_t set_of(const CacheDev& c, uint64_t id) {
@@ -117,11 +116,6 @@ struct Redirect {
     const int64_t* row_map; // null: row pos - begin
 };
 
-__device__ __forceinline__ int64_t readfirstlane_i64(int64_t v) {
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
-    return (int64_t)(((uint64_t)hi << 32) | lo);
-}
 __device__ __forceinline__ uint64_t readlane64(uint64_t v, int src_lane) {
     uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)v, src_lane);
     uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src_lane);
@@ -223,13 +217,7 @@ template <typename V> __device__ __forceinline__ void k1_store(V v, V* p) {
 // SINGLE: the grid has one wave per chunk (every launch up to kK1SingleMaxChunks chunks): no loop and no prefetch state for later
 // chunks, which is what the software pipeline's registers are for -- the short-line kernels drop from 80 to 64 VGPRs or fewer (6 -> 8
 // waves per SIMD), and a launch that is bound by rounds of its waves' dependency chain gets more of them resident.
-// PF: cross-wave prefetch.  A launch on short lines is bound by the length of a wave's dependency chain (ids -> tags -> lines -> stores: DESIGN.md
-// section 4), and the waves of a launch run in rounds, so a wave can shorten the chain of the wave that will take its place: behind its own line loads
-// it touches the tag sets of chunk + pf_waves (one dword per set: the 128-B line lands in the XCD's L2 -- pf_waves is a multiple of 16, so both chunks
-// belong to blocks b and b + 8k, one XCD under round-robin placement; speed only), and behind its stores the ids of chunk + 2 pf_waves, which the wave
-// one round on reads through the SCALAR unit (its own counter: a slow far load never holds up the wave's own vector loads, which return in order).
-// Nothing is consumed: the loads land in registers nobody reads, kept allocated to the end of the kernel.
-template <int CD, int VEC, typename TAG, int NP = 4, bool FULL = false, int NOMISS = 0, bool REDIR = false, bool SINGLE = false, bool PF = false>
+template <int CD, int VEC, typename TAG, int NP = 4, bool FULL = false, int NOMISS = 0, bool REDIR = false, bool SINGLE = false>
 __global__ __launch_bounds__(64 * kK1MaxWaves, K1_MIN_WAVES) void probe_gather_kernel(const int64_t* __restrict__ idx, float* __restrict__ out,
                                                                     int64_t n, uint32_t gen, uint32_t n_blocks, CacheDev c, Redirect rd) {
     // Argument order and the explicit block count are deliberate: with kernarg preloading (build.py: -mllvm -amdgpu-kernarg-preload-count=16)
@@ -293,36 +281,11 @@ __global__ __launch_bounds__(64 * kK1MaxWaves, K1_MIN_WAVES) void probe_gather_k
 
     int64_t chunk = wave;
     Ids ids_next = load_ids(chunk);
-    // (PF) ids of the chunk one round ahead, through the scalar unit: wave-uniform address -> s_load
-    uint32_t pf_sink_a = 0, pf_sink_b = 0;
-    const int64_t far = PF ? readfirstlane_i64(wave) + (int64_t)c.k1_pf_waves : 0;
-    const bool far_on = PF && c.k1_pf_waves != 0 && far < n_chunks;
-    uint64_t far_id[PF ? R : 1];
-    if (PF && far_on) {
-#pragma unroll
-        for (int k = 0; k < R; ++k) far_id[k] = (far * R + k < n) ? (uint64_t)idx[far * R + k] : ~0ull;
-    }
     if (NOMISS == 11) { // (development) ids only
         if (ids_next.id[0] == 0x7FFFFFFFFFFFFFF1ull) out[0] = 1.f;
         return;
     }
     Tags tags = load_tags(ids_next);
-    // (PF) lane q < R (and q + R for the second line of a set of 64-bit tags) gets the address of far row q's tag set; the scalar ids are consumed
-    // here, behind this wave's own tag loads, so that they do not sit in 2R SGPRs through the probe
-    const char* pf_ptr = nullptr;
-    bool pf_go = false;
-    if (PF && far_on) {
-        uint32_t fset = 0;
-#pragma unroll
-        for (int k = 0; k < R; ++k) {
-            const bool ok_k = far_id[k] < c.num_rows;
-            const uint32_t set_k = ok_k ? (uint32_t)set_of(c, far_id[k]) : 0u;
-            if ((lane % R) == k) { fset = set_k; pf_go = ok_k; }
-        }
-        constexpr int LINES = (int)(COALA_WAYS * sizeof(TAG) / 128);   // 128-B lines per set: 1 (32-bit tags) or 2
-        pf_go = pf_go && lane < R * LINES;
-        pf_ptr = reinterpret_cast<const char*>(keys) + (uint64_t)fset * (COALA_WAYS * sizeof(TAG)) + (lane / R) * 128;
-    }
     if (!SINGLE) ids_next = load_ids(chunk + n_waves);
 
     for (; chunk < n_chunks; chunk += n_waves) {
@@ -409,8 +372,6 @@ __global__ __launch_bounds__(64 * kK1MaxWaves, K1_MIN_WAVES) void probe_gather_k
                 if (h && (FULL || u < nunits)) val[p][v] = k1_load(src + u);
             }
         }
-        if (PF && pf_go && chunk == wave) // first chunk only: touch the tag sets of the chunk one round ahead (behind this wave's own line loads)
-            asm volatile("global_load_dword %0, %1, off" : "=v"(pf_sink_a) : "v"(pf_ptr) : "memory");
         if (NOMISS == 13) { // (development) + the line loads of the hit rows, nothing stored
             float acc = 0.f;
 #pragma unroll
@@ -454,16 +415,8 @@ __global__ __launch_bounds__(64 * kK1MaxWaves, K1_MIN_WAVES) void probe_gather_k
             else if ((badmask >> lane) & 1) w = kLinkBad;
             c.miss_link[base + lane] = w;
         }
-        if (PF && c.k1_pf_waves != 0 && chunk == wave) { // ids two rounds ahead: one dword of the chunk's 8R bytes (a chunk never straddles a 128-B line for R <= 16)
-            const int64_t far2 = wave + 2 * (int64_t)c.k1_pf_waves;
-            if (far2 < n_chunks && lane == 0) {
-                const int64_t* p = idx + far2 * R;
-                asm volatile("global_load_dword %0, %1, off" : "=v"(pf_sink_b) : "v"(p) : "memory");
-            }
-        }
         if (SINGLE) break;
     }
-    if (PF) asm volatile("" ::"v"(pf_sink_a), "v"(pf_sink_b)); // the prefetch destinations stay allocated until here
 }
 
 #ifdef COALA_DEV_KNOBS
@@ -879,7 +832,6 @@ struct coala_cache {
                                           // all-hit 123,904 rows: 192.5 / 192.3 / 190.1 / 185.3 us at 2048 / 4096 / 8192 / 16384; 1.08 M x 512 B: 232 -> 227 us
     int k1_waves = kK1Waves;              // K1 waves per block
     bool k1_single = false;               // one wave per chunk, loop-free K1 (development: COALA_K1_SINGLE=1)
-    int k1_pf_blocks = 0;                 // cross-wave prefetch distance of K1 in blocks (development: COALA_K1_PF; rounded to a multiple of 8); 0 = off
     uint64_t rows_total = 0;              // rows submitted since the last stats reset (hits = rows - misses - rejected)
     uint64_t cum_hit = 0, cum_miss = 0;   // totals folded in whenever coala_cache_stats resets the device counters
     uint64_t prof_hit0 = 0, prof_miss0 = 0; // totals at the last profile reset
@@ -1113,7 +1065,6 @@ int coala_cache_create(const coala_cache_config_t* cfg, coala_cache_t** out) {
         if (const char* e = getenv("COALA_K1_GRID")) { int g = atoi(e); if (g >= 1 && g <= 65535) h->k1_grid_cap = g; }
         if (const char* e = getenv("COALA_K1_WAVES")) { int w = atoi(e); if (w == 1 || w == 2 || w == 4) h->k1_waves = w; }
         if (const char* e = getenv("COALA_K1_SINGLE")) h->k1_single = atoi(e) != 0;
-        if (const char* e = getenv("COALA_K1_PF")) { int b = atoi(e); if (b >= 0 && b <= (1 << 20)) h->k1_pf_blocks = (b + 7) & ~7; }
 #endif
         {
             hipPointerAttribute_t attr;
@@ -1276,22 +1227,10 @@ static int read_feature_impl(coala_cache_t* h, float* out, const int64_t* idx, i
                 if (single) {
                     if (redir && full) ps.launch(probe_gather_kernel<CD, VEC, TAG, NPR, true, 0, true, true>, grid, block, idx, out, n, gen, (uint32_t)grid.x, d, rd);
                     else if (redir) ps.launch(probe_gather_kernel<CD, VEC, TAG, NPR, false, 0, true, true>, grid, block, idx, out, n, gen, (uint32_t)grid.x, d, rd);
-                    else if (h->k1_pf_blocks > 0 && chunks > (int64_t)h->k1_pf_blocks * h->k1_waves) {
-                        CacheDev dp = d;
-                        dp.k1_pf_waves = (uint32_t)(h->k1_pf_blocks * h->k1_waves);
-                        if (full) ps.launch(probe_gather_kernel<CD, VEC, TAG, NP, true, 0, false, true, true>, grid, block, idx, out, n, gen, (uint32_t)grid.x, dp, rd);
-                        else ps.launch(probe_gather_kernel<CD, VEC, TAG, NP, false, 0, false, true, true>, grid, block, idx, out, n, gen, (uint32_t)grid.x, dp, rd);
-                    }
                     else if (full) ps.launch(probe_gather_kernel<CD, VEC, TAG, NP, true, 0, false, true>, grid, block, idx, out, n, gen, (uint32_t)grid.x, d, rd);
                     else ps.launch(probe_gather_kernel<CD, VEC, TAG, NP, false, 0, false, true>, grid, block, idx, out, n, gen, (uint32_t)grid.x, d, rd);
                 } else if (redir && full) ps.launch(probe_gather_kernel<CD, VEC, TAG, NPR, true, 0, true>, grid, block, idx, out, n, gen, (uint32_t)grid.x, d, rd);
                 else if (redir) ps.launch(probe_gather_kernel<CD, VEC, TAG, NPR, false, 0, true>, grid, block, idx, out, n, gen, (uint32_t)grid.x, d, rd);
-                else if (h->k1_pf_blocks > 0 && chunks > (int64_t)h->k1_pf_blocks * h->k1_waves) { // cross-wave prefetch: only launches that run in rounds
-                    CacheDev dp = d;
-                    dp.k1_pf_waves = (uint32_t)(h->k1_pf_blocks * h->k1_waves);
-                    if (full) ps.launch(probe_gather_kernel<CD, VEC, TAG, NP, true, 0, false, false, true>, grid, block, idx, out, n, gen, (uint32_t)grid.x, dp, rd);
-                    else ps.launch(probe_gather_kernel<CD, VEC, TAG, NP, false, 0, false, false, true>, grid, block, idx, out, n, gen, (uint32_t)grid.x, dp, rd);
-                }
                 else if (full) ps.launch(probe_gather_kernel<CD, VEC, TAG, NP, true>, grid, block, idx, out, n, gen, (uint32_t)grid.x, d, rd);
                 else ps.launch(probe_gather_kernel<CD, VEC, TAG, NP, false>, grid, block, idx, out, n, gen, (uint32_t)grid.x, d, rd);
             };

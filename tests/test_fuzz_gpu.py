@@ -21,9 +21,7 @@ KNOBS = {2: {"COALA_K2_TILE_ROWS": "0"}, 3: {"COALA_K2_TILE_ROWS": "16", "COALA_
          4: {"COALA_K2_TILE_ROWS": "64", "COALA_K2_GRID": "1", "COALA_K1_GRID": "5"}, 5: {"COALA_K1_WAVES": "4", "COALA_K1_PASSES": "2"},
          6: {"COALA_K2_SPARSE": "64"}, 7: {"COALA_K2_SPARSE": "0"}, 8: {"COALA_K2_SPARSE": "5", "COALA_K2_TILE_ROWS": "32", "COALA_K2_GRID": "2"},
          # rows in flight per wave of the probe+gather kernel: 16 passes (16 / 32 rows per chunk on short lines), 8 passes on a tiny grid
-         9: {"COALA_K1_PASSES": "16"}, 10: {"COALA_K1_PASSES": "8", "COALA_K1_GRID": "3"},
-         # cross-wave prefetch of the probe+gather kernel (a wave touches the tag sets / ids of the chunk 8 / 16 blocks ahead), looping and loop-free forms
-         11: {"COALA_K1_PF": "8"}, 12: {"COALA_K1_PF": "16", "COALA_K1_SINGLE": "1"}}
+         9: {"COALA_K1_PASSES": "16"}, 10: {"COALA_K1_PASSES": "8", "COALA_K1_GRID": "3"}}
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])

@@ -116,6 +116,10 @@ struct Redirect {
     const int64_t* row_map; // null: row pos - begin
 };
 
+template <int CTRL> __device__ __forceinline__ uint32_t dpp_u32(uint32_t v) { // v of the lane the DPP control names (all lanes active)
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+}
+__device__ __forceinline__ uint32_t umin_u32(uint32_t a, uint32_t b) { return a < b ? a : b; }
 __device__ __forceinline__ uint64_t readlane64(uint64_t v, int src_lane) {
     uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)v, src_lane);
     uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src_lane);
@@ -290,66 +294,53 @@ __global__ __launch_bounds__(64 * kK1MaxWaves, K1_MIN_WAVES) void probe_gather_k
 
     for (; chunk < n_chunks; chunk += n_waves) {
         const int64_t base = chunk * R;
-        uint32_t slot[R];       // wave-uniform: set*32 + way for hits
-        int32_t drow[REDIR ? R : 1]; // wave-uniform: destination row in rd.out, -1 = not redirected (REDIR only)
-        uint32_t hitmask = 0;   // bit q: row q hits
-        uint32_t missmask = 0;  // bit q: row q misses (valid, in range, no tag match)
-        uint32_t badmask = 0;   // bit q: id outside [0, num_rows)
-        uint32_t my_set = 0;    // lane q < R: set of row q
+        // ---- probe, all rows of a tag step at once: every lane ranks its own KPL tags, a DPP minimum over the LPS lanes of a row gives
+        //      the lowest matching way (isolated_cache.h:165-172) to each of them, and the row's first lane keeps the books for it.  Nothing
+        //      is extracted row by row into scalars (that was ~80 instructions per row: on short lines the launch was bound by instruction
+        //      issue, 300 VALU + 340 SALU per 8-row wave -- profiles/r03_k1_sq_counters.txt); the copy loops read a row's slot with one
+        //      v_readlane and its status from the ballots.
+        uint32_t slot_v[TSTEPS];                // per lane: set*32 + way of the lane's row (meaningful where the row hits)
+        int32_t drow_v[REDIR ? TSTEPS : 1];     // per lane: destination row of the lane's row in rd.out, -1 = not redirected
+        uint64_t hit_b[TSTEPS], bad_b[TSTEPS];  // ballots: bit l = the row of lane l hits / carries a rejected id
+        bool lead_l[TSTEPS], imiss_l[TSTEPS], bad_l[TSTEPS]; // the lane is the first of an existing row's lanes; ... and that row misses; ... is rejected
+        unsigned long long prev[TSTEPS];
+        const uint32_t lane_way0 = (uint32_t)((lane % TG::LPS) * TG::KPL);
 #pragma unroll
         for (int t = 0; t < TSTEPS; ++t) {
-            uint64_t m[TG::KPL];
+            const TAG want = (TAG)tags.id[t];
+            uint32_t way = 0xFFu;
 #pragma unroll
-            for (int k = 0; k < TG::KPL; ++k) m[k] = __ballot(tags.ok[t] && tags.kk[t][k] == (TAG)tags.id[t]); // tag position k of every lane
-            const uint64_t okm = __ballot(tags.ok[t]);
-            const uint64_t vm = __ballot(tags.valid[t]);
-#pragma unroll
-            for (int qq = 0; qq < TG::SPL; ++qq) {
-                const int q = t * TG::SPL + qq;
-                if (q < R) {
-                    constexpr uint32_t FM = (1u << TG::LPS) - 1u;
-                    uint32_t f[TG::KPL];
-                    uint32_t mm = 0;
-#pragma unroll
-                    for (int k = 0; k < TG::KPL; ++k) {
-                        f[k] = (uint32_t)(m[k] >> (TG::LPS * qq)) & FM;
-                        mm |= f[k];
-                    }
-                    const bool row_valid = (vm >> (TG::LPS * qq)) & 1;
-                    const bool row_ok = (okm >> (TG::LPS * qq)) & 1;
-                    const uint32_t set_q = (uint32_t)__builtin_amdgcn_readlane((int)tags.set[t], TG::LPS * qq);
-                    uint32_t way = 0;
-                    if (mm) { // lowest matching way wins (isolated_cache.h:165-172): way = KPL * lane-in-set + tag position
-                        const int j = __builtin_ctz(mm);
-                        uint32_t kbest = TG::KPL - 1;
-#pragma unroll
-                        for (int k = TG::KPL - 2; k >= 0; --k)
-                            if ((f[k] >> j) & 1) kbest = (uint32_t)k;
-                        way = (uint32_t)(TG::KPL * j) + kbest;
-                        hitmask |= 1u << q;
-                    } else if (row_ok) {
-                        missmask |= 1u << q;
-                    } else if (row_valid) {
-                        badmask |= 1u << q;
-                    }
-                    slot[q] = set_q * COALA_WAYS + way;
-                    if (REDIR) drow[q] = __builtin_amdgcn_readlane(tags.drow[t], TG::LPS * qq);
-                    if (lane == q) my_set = set_q;
-                }
+            for (int k = TG::KPL - 1; k >= 0; --k)
+                if (tags.kk[t][k] == want) way = lane_way0 + (uint32_t)k;
+            if (!tags.ok[t]) way = 0xFFu; // (an id outside the table may equal the empty tag)
+            way = umin_u32(way, dpp_u32<0xB1>(way));   // quad_perm [1,0,3,2]: lane ^ 1
+            way = umin_u32(way, dpp_u32<0x4E>(way));   // quad_perm [2,3,0,1]: lane ^ 2
+            way = umin_u32(way, dpp_u32<0x141>(way));  // row_half_mirror: the other quad of the 8 lanes
+            if (TG::LPS == 16) way = umin_u32(way, dpp_u32<0x140>(way)); // row_mirror: the other half of the 16 lanes
+            const bool hit = way != 0xFFu;
+            slot_v[t] = tags.set[t] * COALA_WAYS + (way & (COALA_WAYS - 1));
+            if (REDIR) drow_v[t] = tags.drow[t];
+            hit_b[t] = __ballot(hit);
+            bad_l[t] = tags.valid[t] && !tags.ok[t];
+            bad_b[t] = __ballot(bad_l[t]);
+            lead_l[t] = tags.valid[t] && (lane % TG::LPS) == 0;
+            // ---- misses: push the row on its set's chain (the old head comes back behind the row loads)
+            imiss_l[t] = NOMISS == 0 && lead_l[t] && tags.ok[t] && !hit;
+            prev[t] = 0;
+            if (imiss_l[t]) {
+                const unsigned long long tag = ((unsigned long long)gen << 32) | (unsigned long long)(base + t * TG::SPL + lane / TG::LPS + 1);
+                prev[t] = atomicExch(reinterpret_cast<unsigned long long*>(c.set_head + tags.set[t]), tag);
+                // (the set's round-robin cursor, isolated_cache.h:203, is advanced by K2: an atomicAdd here cost 1.2 us per launch)
             }
         }
-        if (NOMISS == 12) { // (development) ids + tag sets + ballots
-            if ((hitmask ^ (missmask << 1) ^ my_set) == 0xFFFFFFF7u) out[0] = 1.f;
+        if (NOMISS == 12) { // (development) ids + tag sets + the probe
+            if ((hit_b[0] ^ bad_b[0]) == 0x123456789ABCDEFull && lead_l[0]) out[0] = 1.f;
             return;
         }
-        // ---- misses: push the row on its set's chain (the old head comes back behind the row loads)
-        const bool i_miss = NOMISS == 0 && lane < R && ((missmask >> lane) & 1);
-        unsigned long long prev = 0;
-        if (i_miss) {
-            const unsigned long long tag = ((unsigned long long)gen << 32) | (unsigned long long)(base + lane + 1);
-            prev = atomicExch(reinterpret_cast<unsigned long long*>(c.set_head + my_set), tag);
-            // (the set's round-robin cursor, isolated_cache.h:203, is advanced by K2: an atomicAdd here cost 1.2 us per launch)
-        }
+        // row q of the chunk: its tag step, and the first of its lanes there
+        auto row_slot = [&](int q) { return (uint32_t)__builtin_amdgcn_readlane((int)slot_v[q / TG::SPL], TG::LPS * (q % TG::SPL)); };
+        auto row_hit = [&](int q) { return ((hit_b[q / TG::SPL] >> (TG::LPS * (q % TG::SPL))) & 1) != 0; };
+        auto row_bad = [&](int q) { return ((bad_b[q / TG::SPL] >> (TG::LPS * (q % TG::SPL))) & 1) != 0; };
         // ids two chunks ahead (consumed by load_tags in the NEXT iteration: a full row round trip of slack)
         Ids ids_next2;
         if (!SINGLE) ids_next2 = load_ids(chunk + 2 * n_waves);
@@ -362,9 +353,8 @@ __global__ __launch_bounds__(64 * kK1MaxWaves, K1_MIN_WAVES) void probe_gather_k
         V val[G::PASSES][G::VPL];
 #pragma unroll
         for (int p = 0; p < G::PASSES; ++p) {
-            const int q = p * G::RPP + sub;
-            const uint32_t s = (G::RPP == 2) ? (sub ? slot[p * G::RPP + (G::RPP - 1)] : slot[p * G::RPP]) : slot[p];
-            const bool h = (hitmask >> q) & 1;
+            const uint32_t s = (G::RPP == 2) ? (sub ? row_slot(p * G::RPP + (G::RPP - 1)) : row_slot(p * G::RPP)) : row_slot(p);
+            const bool h = (G::RPP == 2) ? (sub ? row_hit(p * G::RPP + (G::RPP - 1)) : row_hit(p * G::RPP)) : row_hit(p);
             const V* src = reinterpret_cast<const V*>(c.lines + (uint64_t)s * CD);
 #pragma unroll
             for (int v = 0; v < G::VPL; ++v) {
@@ -376,7 +366,7 @@ __global__ __launch_bounds__(64 * kK1MaxWaves, K1_MIN_WAVES) void probe_gather_k
             float acc = 0.f;
 #pragma unroll
             for (int p = 0; p < G::PASSES; ++p) {
-                const bool h = (hitmask >> (p * G::RPP + sub)) & 1;
+                const bool h = (G::RPP == 2) ? (sub ? row_hit(p * G::RPP + (G::RPP - 1)) : row_hit(p * G::RPP)) : row_hit(p);
 #pragma unroll
                 for (int v = 0; v < G::VPL; ++v)
                     if (h && (FULL || (uint32_t)(v * G::LPR + l_in) < nunits)) acc += first_of(val[p][v]);
@@ -391,11 +381,12 @@ __global__ __launch_bounds__(64 * kK1MaxWaves, K1_MIN_WAVES) void probe_gather_k
 #pragma unroll
         for (int p = 0; p < G::PASSES; ++p) {
             const int q = p * G::RPP + sub;
-            const bool h = (hitmask >> q) & 1;
-            const bool bad = (badmask >> q) & 1;
+            const bool h = (G::RPP == 2) ? (sub ? row_hit(p * G::RPP + (G::RPP - 1)) : row_hit(p * G::RPP)) : row_hit(p);
+            const bool bad = (G::RPP == 2) ? (sub ? row_bad(p * G::RPP + (G::RPP - 1)) : row_bad(p * G::RPP)) : row_bad(p);
             V* dst = reinterpret_cast<V*>(out + (base + q) * (int64_t)c.dim);
             if (REDIR) {
-                const int32_t dr = (G::RPP == 2) ? (sub ? drow[p * G::RPP + (G::RPP - 1)] : drow[p * G::RPP]) : drow[p];
+                auto row_drow = [&](int r) { return (int32_t)__builtin_amdgcn_readlane(drow_v[r / TG::SPL], TG::LPS * (r % TG::SPL)); };
+                const int32_t dr = (G::RPP == 2) ? (sub ? row_drow(p * G::RPP + (G::RPP - 1)) : row_drow(p * G::RPP)) : row_drow(p);
                 if (dr >= 0) dst = reinterpret_cast<V*>(rd.out + (int64_t)dr * (int64_t)c.dim);
             }
 #pragma unroll
@@ -407,13 +398,16 @@ __global__ __launch_bounds__(64 * kK1MaxWaves, K1_MIN_WAVES) void probe_gather_k
                 }
             }
         }
-        // ---- verdict for K2: one word per position, written for EVERY row of the chunk (one 4-byte store per lane q < R), so the
-        //      array never needs clearing between batches
-        if (NOMISS == 0 && lane < R && base + lane < n) {
-            uint32_t w = 0u;
-            if (i_miss) w = kLinkMiss | (((uint32_t)(prev >> 32) == gen) ? (uint32_t)prev : 0u);
-            else if ((badmask >> lane) & 1) w = kLinkBad;
-            c.miss_link[base + lane] = w;
+        // ---- verdict for K2: one word per position, written for EVERY row of the chunk (one 4-byte store by the first lane of the
+        //      row), so the array never needs clearing between batches
+#pragma unroll
+        for (int t = 0; t < TSTEPS; ++t) {
+            if (NOMISS == 0 && lead_l[t]) {
+                uint32_t w = 0u;
+                if (imiss_l[t]) w = kLinkMiss | (((uint32_t)(prev[t] >> 32) == gen) ? (uint32_t)prev[t] : 0u);
+                else if (bad_l[t]) w = kLinkBad;
+                c.miss_link[base + t * TG::SPL + lane / TG::LPS] = w;
+            }
         }
         if (SINGLE) break;
     }

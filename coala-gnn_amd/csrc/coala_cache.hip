@@ -117,7 +117,7 @@ struct Redirect {
 };
 
 template <int CTRL> __device__ __forceinline__ uint32_t dpp_u32(uint32_t v) { // v of the lane the DPP control names (all lanes active)
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true);   // (this form folds into the consuming v_min_u32: one instruction per step)
 }
 __device__ __forceinline__ uint32_t umin_u32(uint32_t a, uint32_t b) { return a < b ? a : b; }
 __device__ __forceinline__ uint64_t readlane64(uint64_t v, int src_lane) {
@@ -353,8 +353,11 @@ __global__ __launch_bounds__(64 * kK1MaxWaves, K1_MIN_WAVES) void probe_gather_k
         V val[G::PASSES][G::VPL];
 #pragma unroll
         for (int p = 0; p < G::PASSES; ++p) {
-            const uint32_t s = (G::RPP == 2) ? (sub ? row_slot(p * G::RPP + (G::RPP - 1)) : row_slot(p * G::RPP)) : row_slot(p);
-            const bool h = (G::RPP == 2) ? (sub ? row_hit(p * G::RPP + (G::RPP - 1)) : row_hit(p * G::RPP)) : row_hit(p);
+            // (both rows of a pass are read out BEFORE the per-lane choice: a readlane inside a divergent ?: becomes a branch per pass)
+            const uint32_t s_a = row_slot(p * G::RPP), s_b = row_slot(p * G::RPP + (G::RPP - 1));
+            const bool h_a = row_hit(p * G::RPP), h_b = row_hit(p * G::RPP + (G::RPP - 1));
+            const uint32_t s = (G::RPP == 2 && sub) ? s_b : s_a;
+            const bool h = (G::RPP == 2 && sub) ? h_b : h_a;
             const V* src = reinterpret_cast<const V*>(c.lines + (uint64_t)s * CD);
 #pragma unroll
             for (int v = 0; v < G::VPL; ++v) {
@@ -366,7 +369,8 @@ __global__ __launch_bounds__(64 * kK1MaxWaves, K1_MIN_WAVES) void probe_gather_k
             float acc = 0.f;
 #pragma unroll
             for (int p = 0; p < G::PASSES; ++p) {
-                const bool h = (G::RPP == 2) ? (sub ? row_hit(p * G::RPP + (G::RPP - 1)) : row_hit(p * G::RPP)) : row_hit(p);
+                const bool h_a = row_hit(p * G::RPP), h_b = row_hit(p * G::RPP + (G::RPP - 1));
+                const bool h = (G::RPP == 2 && sub) ? h_b : h_a;
 #pragma unroll
                 for (int v = 0; v < G::VPL; ++v)
                     if (h && (FULL || (uint32_t)(v * G::LPR + l_in) < nunits)) acc += first_of(val[p][v]);
@@ -381,12 +385,15 @@ __global__ __launch_bounds__(64 * kK1MaxWaves, K1_MIN_WAVES) void probe_gather_k
 #pragma unroll
         for (int p = 0; p < G::PASSES; ++p) {
             const int q = p * G::RPP + sub;
-            const bool h = (G::RPP == 2) ? (sub ? row_hit(p * G::RPP + (G::RPP - 1)) : row_hit(p * G::RPP)) : row_hit(p);
-            const bool bad = (G::RPP == 2) ? (sub ? row_bad(p * G::RPP + (G::RPP - 1)) : row_bad(p * G::RPP)) : row_bad(p);
+            const bool h_a = row_hit(p * G::RPP), h_b = row_hit(p * G::RPP + (G::RPP - 1));
+            const bool bad_a = row_bad(p * G::RPP), bad_b2 = row_bad(p * G::RPP + (G::RPP - 1));
+            const bool h = (G::RPP == 2 && sub) ? h_b : h_a;
+            const bool bad = (G::RPP == 2 && sub) ? bad_b2 : bad_a;
             V* dst = reinterpret_cast<V*>(out + (base + q) * (int64_t)c.dim);
             if (REDIR) {
                 auto row_drow = [&](int r) { return (int32_t)__builtin_amdgcn_readlane(drow_v[r / TG::SPL], TG::LPS * (r % TG::SPL)); };
-                const int32_t dr = (G::RPP == 2) ? (sub ? row_drow(p * G::RPP + (G::RPP - 1)) : row_drow(p * G::RPP)) : row_drow(p);
+                const int32_t dr_a = row_drow(p * G::RPP), dr_b = row_drow(p * G::RPP + (G::RPP - 1));
+                const int32_t dr = (G::RPP == 2 && sub) ? dr_b : dr_a;
                 if (dr >= 0) dst = reinterpret_cast<V*>(rd.out + (int64_t)dr * (int64_t)c.dim);
             }
 #pragma unroll

@@ -9,9 +9,11 @@
 //
 // Design (DESIGN.md has the long form).  One call = one batch, two stream-ordered kernels, no same-address atomics:
 //   K1 probe_gather : a wave takes R rows (4, or 8 for 512-B lines) per step of a grid-stride loop.  One 16-B load per
-//                     lane fetches the 32 tags of four sets at once (16 lanes x 2 keys per set), two ballots find the
-//                     matching way, hits are copied HBM line -> output row with nontemporal 16-B loads/stores, 4 rows in
-//                     flight per wave, with the next chunk's ids/tags prefetched behind them.  A miss is pushed on its
+//                     lane fetches the 32 tags of eight sets at once (8 lanes x 4 tags of 32 bits per set; four sets of
+//                     16 lanes x 2 tags with the reference's 64-bit tags); every lane ranks its own tags and a DPP minimum
+//                     over the lanes of a row gives the lowest matching way -- all rows at once, nothing extracted row by
+//                     row; hits are copied HBM line -> output row with nontemporal 16-B loads / plain stores, 4 row(-pair)s
+//                     in flight per wave, with the next chunk's ids/tags prefetched behind them.  A miss is pushed on its
 //                     set's chain (ONE atomicExch on the set's own head word, tagged with the batch generation so no
 //                     clearing pass is needed); every row's verdict + chain link is one 4-byte word written per position.
 //   K2 miss_fill    : same chunking.  For a missed row one lane walks the set's chain and counts the misses that precede
@@ -217,7 +219,7 @@ template <typename V> __device__ __forceinline__ void k1_store(V v, V* p) {
 
 // NOMISS is a development switch (tools/k1_insitu.py --stages: where a launch's time goes; such launches run on a generation nobody
 // consumes): 0 = the product kernel; 1 = no miss bookkeeping; 11 / 12 / 13 = the dependency chain cut short after the id loads /
-// after the tag loads and ballots / after the line loads of the hit rows (no stores).
+// after the tag loads and the probe / after the line loads of the hit rows (no stores).
 // SINGLE: the grid has one wave per chunk (every launch up to kK1SingleMaxChunks chunks): no loop and no prefetch state for later
 // chunks, which is what the software pipeline's registers are for -- the short-line kernels drop from 80 to 64 VGPRs or fewer (6 -> 8
 // waves per SIMD), and a launch that is bound by rounds of its waves' dependency chain gets more of them resident.

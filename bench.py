@@ -476,9 +476,12 @@ def _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, dev
     batches = [ids_for(args.prewarm + s) for s in range(args.warmup + args.steps)]  # resident in HBM before timing
     torch.cuda.synchronize()
 
+    import collections
+    warm_live = collections.deque(maxlen=3)   # (as in the timed region: three delivered tensors alive, so that its allocator blocks exist before the clock runs)
     for s in range(args.warmup):
-        manager.fetch_feature(batches[s])
+        warm_live.append(manager.fetch_feature(batches[s])[-1])
     torch.cuda.synchronize()
+    warm_live.clear()
     # parity self-check on every rank, untimed: the rows this path just delivered == the synthetic table's formula, bit for bit.
     # (At N>1 this is the first time the exchange runs over real RCCL links: a wrong row must stop the run, not be timed.)
     # (with --warmup 0 batches[0] is the first TIMED minibatch: checking it here would cache its rows ahead of the clock)
@@ -516,6 +519,8 @@ def _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, dev
     gc.collect()
     gc.freeze()
     gc.disable()   # ... and none at all while the clock runs (re-enabled right behind the region)
+    import collections
+    live = collections.deque(maxlen=3)   # the last three delivered tensors stay referenced, as a loader's pipeline holds them (see roofline_allhit)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -528,12 +533,14 @@ def _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, dev
             counts_for(s + 1)
         out = manager.fetch_feature(batches[s])[-1]
         rows_done += out.shape[0]
+        live.append(out)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_start
     gc.enable()
+    live.clear()
 
     hit, miss, bad = cache.stats()
     prof = cache.profile()
@@ -623,12 +630,21 @@ def _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, dev
                 manager.fetch_feature((ids,))
         torch.cuda.synchronize()
 
-        def k1_figures(id_list, launches):
+        def k1_figures(id_list, launches, live_outputs):
+            # live_outputs: how many delivered tensors stay referenced, as a loader's pipeline holds them.  With none kept, torch's allocator hands the
+            # SAME block back for every fetch: the 151 MB of rows written by one launch are still in the 256 MiB Infinity Cache when the next one
+            # overwrites them, the writes never reach HBM and the kernel reads 0.80 instead of 0.62-0.65 (profiles/r03_k1_old_vs_new.txt)
+            import collections
+            ring = collections.deque(maxlen=max(live_outputs, 1))
             cache.stats(reset=True)
             cache.profile(reset=True)
             for k in range(launches):
-                manager.fetch_feature((id_list[k % len(id_list)],))
+                o = manager.fetch_feature((id_list[k % len(id_list)],))[-1]
+                if live_outputs:
+                    ring.append(o)
+                del o
             torch.cuda.synchronize()
+            ring.clear()
             h2, m2, _ = cache.stats()
             p2 = cache.profile()
             l2 = max(p2.gather_launches, 1)
@@ -639,8 +655,8 @@ def _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, dev
                     "frac_of_box_streaming_copy": round(ach2 / box_copy, 4) if box_copy else None,
                     "avg_launch_us": round(us2, 2), "launches": int(p2.gather_launches), "rows_per_launch": round(p2.gather_rows / l2, 1),
                     "hit_ratio": round(h2 / max(h2 + m2, 1), 4), "alg_bytes_per_launch": int(b2 / l2), "no_miss_fill_launch_us": round(p2.fill_ms / max(p2.fill_launches, 1) * 1e3, 2)}
-        steady = k1_figures(id_sets, args.allhit_launches)
-        warm = k1_figures(id_sets[:1], args.allhit_launches)
+        steady = k1_figures(id_sets, args.allhit_launches, 3)
+        warm = k1_figures(id_sets[:1], args.allhit_launches, 0)
         # (c) probe-only launches (coala_cache_serve_probe + serve_abort: K1 alone, the same kernel on the same ids), no events attached
         out_buf = torch.empty((max_rows, args.dim), dtype=torch.float32, device=device)
         one = id_sets[0][:1].contiguous()
@@ -672,9 +688,11 @@ def _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, dev
         cache.profile(reset=True)
         roofline_allhit = {"bound": "hbm", "kernel": "probe_gather_kernel", **steady, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "id_sets_in_rotation": n_sets, "bytes_between_two_uses_of_a_set_MB": int((n_sets - 1) * 2 * max_rows * args.dim * 4 / 1e6),
-                           "mall_warm": {**warm, "note": "ONE id set re-fetched back to back: its lines / rows are partly served by the 256 MiB Infinity Cache -- not an HBM figure"},
+                           "output_tensors_kept_alive": 3,
+                           "mall_warm": {**warm, "note": "ONE id set re-fetched back to back into ONE output block (nothing kept alive: the allocator returns the same block): the rows "
+                                                         "written by one launch are overwritten in the 256 MiB Infinity Cache by the next -- not an HBM figure; this is what `frac` was until round 3"},
                            "back_to_back_check": b2b,
-                           "note": "untimed extra leg: every row a hit (pre-warmed unique uniform ids), steady state over rotating disjoint id sets"}
+                           "note": "untimed extra leg: every row a hit (pre-warmed unique uniform ids), steady state over rotating disjoint id sets, the last three output tensors kept alive"}
 
     # the kernel that dominates the STEP TIME on this workload is the cold fill, bound by the host link, not by HBM
     fill_launches = max(prof.fill_launches, 1)

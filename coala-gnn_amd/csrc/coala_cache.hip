@@ -178,7 +178,7 @@ struct Geo {
 // per chunk or per wave serialises at ~12 ns per same-address atomic -- 4096 waves = 49 us, as long as the whole hit
 // gather; a block-level append needs LDS staging and a trailing barrier and still costs 5-7 us.)
 #ifndef K1_MIN_WAVES
-#define K1_MIN_WAVES 4 // waves per SIMD the register allocator must leave room for
+#define K1_MIN_WAVES 4 // waves per SIMD the register allocator must leave room for (5 on 4-KiB lines spills: 17.5 -> 20.9 us on the default workload)
 #endif
 // Row(-pair)s a wave keeps in flight (passes): 4 for every line size and both tag widths = 16 KiB of 4-KiB lines, 4 KiB of 512-B lines
 // (8 rows).  More passes on short lines were measured in situ on the configs[3] shape (512-B lines, 16 GiB cache, 315 k rows per
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(64 * kK1MaxWaves, K1_MIN_WAVES) void probe_gather_k
     constexpr int R = G::R;
     static_assert(R <= 32, "per-chunk row masks are 32 bits wide");
     constexpr int TSTEPS = (R + TG::SPL - 1) / TG::SPL; // tag loads per chunk: SPL sets per wave-wide 16-B load (LPS lanes x KPL tags per set)
-    const int lane = threadIdx.x & 63;
+    int lane = threadIdx.x & 63;
 #ifdef COALA_DEV_KNOBS
     const int wpb = (int)(blockDim.x >> 6);
 #else
@@ -295,6 +295,9 @@ __global__ __launch_bounds__(64 * kK1MaxWaves, K1_MIN_WAVES) void probe_gather_k
     if (!SINGLE) ids_next = load_ids(chunk + n_waves);
 
     for (; chunk < n_chunks; chunk += n_waves) {
+        // (the lane index made opaque once per iteration: otherwise every lane-derived address and constant of the loop is hoisted into a VGPR of its
+        //  own -- 72 -> 66 VGPRs on 512-B lines, 81 -> 67 in the redirecting variant: one more wave per SIMD -- for a loop most waves run once)
+        asm volatile("" : "+v"(lane));
         const int64_t base = chunk * R;
         // ---- probe, all rows of a tag step at once: every lane ranks its own KPL tags, a DPP minimum over the LPS lanes of a row gives
         //      the lowest matching way (isolated_cache.h:165-172) to each of them, and the row's first lane keeps the books for it.  Nothing

@@ -136,8 +136,8 @@ for rep in range(int(os.environ.get("REPS", 2))):
             torch.cuda.synchronize()
             cache.stats(reset=True)
             cache.profile(reset=True)
-            for _ in range(100):
-                cache.read_feature(out.data_ptr(), ids.data_ptr(), ids.numel())
+            for k in range(100):
+                cache.read_feature(outs[k % len(outs)].data_ptr(), ids.data_ptr(), ids.numel())
             torch.cuda.synchronize()
             p = cache.profile()
             alg = p.gather_rows * (8 + tagb) + p.gather_hits * 2 * dim * 4

@@ -658,20 +658,20 @@ def _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, dev
         steady = k1_figures(id_sets, args.allhit_launches, 3)
         warm = k1_figures(id_sets[:1], args.allhit_launches, 0)
         # (c) probe-only launches (coala_cache_serve_probe + serve_abort: K1 alone, the same kernel on the same ids), no events attached
-        out_buf = torch.empty((max_rows, args.dim), dtype=torch.float32, device=device)
+        out_bufs = [torch.empty((max_rows, args.dim), dtype=torch.float32, device=device) for _ in range(3)]   # in rotation, like the delivered tensors above
         one = id_sets[0][:1].contiguous()
         b2b = {}
         try:
             for name, lists, nrow in (("rotating_sets", id_sets, max_rows), ("one_row_batch", [one], 1)):
                 for ids in lists:                                         # untimed pass (profiling flag off path is the same kernel)
-                    cache.serve_probe(out_buf.data_ptr(), ids.data_ptr(), nrow)
+                    cache.serve_probe(out_bufs[0].data_ptr(), ids.data_ptr(), nrow)
                     cache.serve_abort()
                 torch.cuda.synchronize()
                 n_b2b = 60
                 ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev_a.record()
                 for k in range(n_b2b):
-                    cache.serve_probe(out_buf.data_ptr(), lists[k % len(lists)].data_ptr(), nrow)
+                    cache.serve_probe(out_bufs[k % 3].data_ptr(), lists[k % len(lists)].data_ptr(), nrow)
                     cache.serve_abort()
                 ev_b.record()
                 ev_b.synchronize()
@@ -683,7 +683,7 @@ def _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, dev
                            "(avg_launch_us, what `frac` uses) must lie between the two.")
         except Exception as e:  # noqa: BLE001 -- a diagnostic: never costs the line
             b2b = {"error": repr(e)[:200]}
-        del out_buf
+        del out_bufs
         cache.stats(reset=True)
         cache.profile(reset=True)
         roofline_allhit = {"bound": "hbm", "kernel": "probe_gather_kernel", **steady, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -87,7 +87,7 @@ def summarize(path, last_steps):
     ev = []
     for r in rows:
         name = r["Kernel_Name"]
-        kind = "fill" if "miss_fill_kernel" in name else ("copy" if "copyBuffer" in name else ("probe" if "probe_gather_kernel" in name else None))
+        kind = "fill" if "miss_fill_kernel" in name else ("copy" if ("copyBuffer" in name or "inproc_copy_kernel" in name) else ("probe" if "probe_gather_kernel" in name else None))
         if kind:
             ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), kind, r.get("Queue_Id", "?")))
     ev.sort()

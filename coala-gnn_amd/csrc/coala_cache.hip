@@ -221,8 +221,9 @@ template <typename V> __device__ __forceinline__ void k1_store(V v, V* p) {
 // consumes): 0 = the product kernel; 1 = no miss bookkeeping; 11 / 12 / 13 = the dependency chain cut short after the id loads /
 // after the tag loads and the probe / after the line loads of the hit rows (no stores).
 // SINGLE: the grid has one wave per chunk (every launch up to kK1SingleMaxChunks chunks): no loop and no prefetch state for later
-// chunks, which is what the software pipeline's registers are for -- the short-line kernels drop from 80 to 64 VGPRs or fewer (6 -> 8
-// waves per SIMD), and a launch that is bound by rounds of its waves' dependency chain gets more of them resident.
+// chunks, which is what the software pipeline's registers are for (4-KiB lines: 76 instead of 110 VGPRs, 6 instead of 4 waves per SIMD) and
+// whose id / tag loads a one-chunk wave issues for chunks it never has.  The product's choice for lines of 1 KiB and more; 512-B lines keep
+// the looping kernel (8-row waves gain from the pipeline whenever a wave does run two chunks, and lose nothing when it does not).
 template <int CD, int VEC, typename TAG, int NP = 4, bool FULL = false, int NOMISS = 0, bool REDIR = false, bool SINGLE = false>
 __global__ __launch_bounds__(64 * kK1MaxWaves, K1_MIN_WAVES) void probe_gather_kernel(const int64_t* __restrict__ idx, float* __restrict__ out,
                                                                     int64_t n, uint32_t gen, uint32_t n_blocks, CacheDev c, Redirect rd) {
@@ -837,7 +838,7 @@ struct coala_cache {
                                           // hits in situ: 2048 blocks -> 22.3 us, 4096 -> 20.7, 8192 -> 20.6; all-hit 36,864 rows: 53.8 / 53.1 / 51.4 us;
                                           // all-hit 123,904 rows: 192.5 / 192.3 / 190.1 / 185.3 us at 2048 / 4096 / 8192 / 16384; 1.08 M x 512 B: 232 -> 227 us
     int k1_waves = kK1Waves;              // K1 waves per block
-    bool k1_single = false;               // one wave per chunk, loop-free K1 (development: COALA_K1_SINGLE=1)
+    int k1_single = -1;                   // one wave per chunk, loop-free K1: -1 = by line size (lines of 1 KiB and more), 0 / 1 = COALA_K1_SINGLE of the development build
     uint64_t rows_total = 0;              // rows submitted since the last stats reset (hits = rows - misses - rejected)
     uint64_t cum_hit = 0, cum_miss = 0;   // totals folded in whenever coala_cache_stats resets the device counters
     uint64_t prof_hit0 = 0, prof_miss0 = 0; // totals at the last profile reset
@@ -1070,7 +1071,7 @@ int coala_cache_create(const coala_cache_config_t* cfg, coala_cache_t** out) {
         if (const char* e = getenv("COALA_K1_PASSES")) { int v = atoi(e); if (v == 2 || v == 4 || v == 8 || v == 16) h->k1_passes = v; }
         if (const char* e = getenv("COALA_K1_GRID")) { int g = atoi(e); if (g >= 1 && g <= 65535) h->k1_grid_cap = g; }
         if (const char* e = getenv("COALA_K1_WAVES")) { int w = atoi(e); if (w == 1 || w == 2 || w == 4) h->k1_waves = w; }
-        if (const char* e = getenv("COALA_K1_SINGLE")) h->k1_single = atoi(e) != 0;
+        if (const char* e = getenv("COALA_K1_SINGLE")) h->k1_single = atoi(e) != 0 ? 1 : 0;
 #endif
         {
             hipPointerAttribute_t attr;
@@ -1228,7 +1229,11 @@ static int read_feature_impl(coala_cache_t* h, float* out, const int64_t* idx, i
                 using GK = Geo<CD, VEC, NP>;
                 using GR = Geo<CD, VEC, NPR>;
                 const int64_t chunks = redir ? (n + GR::R - 1) / GR::R : (n + GK::R - 1) / GK::R;
-                const bool single = h->k1_single && chunks <= kK1SingleMaxChunks;   // one wave per chunk, no loop
+                // one wave per chunk, no loop, no prefetch state for later chunks: with the lane-parallel probe it is ahead on every line of 1 KiB and more
+                // (default workload 17.5 -> 16.35 us, its all-hit leg 58.8 -> 56.6 us, 262,144 x 1 KiB and 123,904 x 4 KiB at every hit ratio:
+                // profiles/r03_k1_single_lane_parallel.txt) and behind on 512-B lines, whose 8-row waves need the software pipeline (12.3 vs 13.3 us at 72 k rows)
+                const bool want_single = h->k1_single < 0 ? (CD >= 256) : (h->k1_single != 0);
+                const bool single = want_single && chunks <= kK1SingleMaxChunks;
                 const dim3 grid(grid_for(chunks, h->k1_waves, single ? (int)((kK1SingleMaxChunks + h->k1_waves - 1) / h->k1_waves) : h->k1_grid_cap)), block(64 * h->k1_waves);
                 if (single) {
                     if (redir && full) ps.launch(probe_gather_kernel<CD, VEC, TAG, NPR, true, 0, true, true>, grid, block, idx, out, n, gen, (uint32_t)grid.x, d, rd);

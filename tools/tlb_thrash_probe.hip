@@ -119,6 +119,19 @@ __global__ __launch_bounds__(256) void thrash(const vu32x4* __restrict__ buf, co
 
 __global__ void empty_kernel() {}
 
+// plain streaming copy (16 B per lane, 4 loads in flight per lane, nontemporal loads, plain stores): what the memory system gives a read + write kernel with
+// perfectly sequential addresses -- the ceiling of K1's all-hit launch (151 MB of lines in, 151 MB of rows out)
+__global__ __launch_bounds__(256) void stream_copy(const vu32x4* __restrict__ src, vu32x4* __restrict__ dst, size_t n_vec) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n_vec; i += 4 * stride) {
+        vu32x4 v0 = __builtin_nontemporal_load(src + i), v1 = __builtin_nontemporal_load(src + i + stride);
+        vu32x4 v2 = __builtin_nontemporal_load(src + i + 2 * stride), v3 = __builtin_nontemporal_load(src + i + 3 * stride);
+        dst[i] = v0; dst[i + stride] = v1; dst[i + 2 * stride] = v2; dst[i + 3 * stride] = v3;
+    }
+    for (; i < n_vec; i += stride) dst[i] = __builtin_nontemporal_load(src + i);
+}
+
 // latency: ONE wave walks a chain of random 512-B lines (the first dword of a line names the next one); ns per dependent hop
 __global__ void chain_init(vu32x4* buf, const uint32_t* seq, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -208,6 +221,19 @@ int main() {
             printf("dependent chain of %d random 512-B lines of the 16 GiB buffer, one wave, %s: %6.1f ns per hop\n", n_chain, pass ? "walked again (cache-resident)" : "from HBM                     ", (s.mn - 6.0) * 1e3 / n_chain);
         }
         CHK(hipFree(d_seq));
+    }
+    {   // streaming copy of 151 MB (one all-hit launch of 36,864 x 4 KiB), sources rotating over 5 regions of the 16 GiB buffer, destinations over 1 or 3 buffers
+        const size_t cbytes = (size_t)36864 * 4096, n_vec = cbytes / 16;
+        vu32x4* dsts[3];
+        for (auto& d : dsts) CHK(hipMalloc((void**)&d, cbytes));
+        for (unsigned grid : {2048u, 8192u}) {
+            for (int nd : {1, 3}) {
+                auto s = timed(REPS, [](int) {}, [&](int r) { hipLaunchKernelGGL(stream_copy, dim3(grid), dim3(256), 0, 0, buf + (size_t)(r % 5) * (1ull << 26), dsts[r % nd], n_vec); });
+                printf("streaming copy of %.0f MB, %u blocks, %d destination buffer(s) in rotation: %6.1f / %6.1f us  = %6.0f GB/s read + written (min, bracket of ~6 us included)\n",
+                       cbytes / 1e6, grid, nd, s.mean, s.mn, 2.0 * cbytes / (s.mn * 1e-6) / 1e9);
+            }
+        }
+        for (auto& d : dsts) CHK(hipFree(d));
     }
     for (int64_t n : {(int64_t)43008, (int64_t)196608}) {
         uint32_t *d_list[REPS], *d_blist[REPS], *d_off[REPS], *d_xcc;

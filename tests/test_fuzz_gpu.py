@@ -21,7 +21,10 @@ KNOBS = {2: {"COALA_K2_TILE_ROWS": "0"}, 3: {"COALA_K2_TILE_ROWS": "16", "COALA_
          4: {"COALA_K2_TILE_ROWS": "64", "COALA_K2_GRID": "1", "COALA_K1_GRID": "5"}, 5: {"COALA_K1_WAVES": "4", "COALA_K1_PASSES": "2"},
          6: {"COALA_K2_SPARSE": "64"}, 7: {"COALA_K2_SPARSE": "0"}, 8: {"COALA_K2_SPARSE": "5", "COALA_K2_TILE_ROWS": "32", "COALA_K2_GRID": "2"},
          # rows in flight per wave of the probe+gather kernel: 16 passes (16 / 32 rows per chunk on short lines), 8 passes on a tiny grid
-         9: {"COALA_K1_PASSES": "16"}, 10: {"COALA_K1_PASSES": "8", "COALA_K1_GRID": "3"}}
+         9: {"COALA_K1_PASSES": "16"}, 10: {"COALA_K1_PASSES": "8", "COALA_K1_GRID": "3"},
+         # the product takes the loop-free probe+gather kernel on lines of 1 KiB and more and the looping one on 512-B lines (and on batches beyond 1 M chunks):
+         # the looping kernel on every line size, the loop-free one on every line size
+         11: {"COALA_K1_SINGLE": "0"}, 12: {"COALA_K1_SINGLE": "1"}, 13: {"COALA_K1_SINGLE": "0", "COALA_K1_GRID": "2", "COALA_K1_WAVES": "1"}}
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])

@@ -15,6 +15,7 @@ launches in the timed region, on the stream it is launched on -- the kernel's ow
 rocprofv3 reports) and "cpu_baseline" (the C oracle, one host core, bounded sample).
 """
 import argparse
+import collections
 import json
 import os
 import sys
@@ -476,7 +477,6 @@ def _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, dev
     batches = [ids_for(args.prewarm + s) for s in range(args.warmup + args.steps)]  # resident in HBM before timing
     torch.cuda.synchronize()
 
-    import collections
     warm_live = collections.deque(maxlen=3)   # (as in the timed region: three delivered tensors alive, so that its allocator blocks exist before the clock runs)
     for s in range(args.warmup):
         warm_live.append(manager.fetch_feature(batches[s])[-1])
@@ -519,7 +519,6 @@ def _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, dev
     gc.collect()
     gc.freeze()
     gc.disable()   # ... and none at all while the clock runs (re-enabled right behind the region)
-    import collections
     live = collections.deque(maxlen=3)   # the last three delivered tensors stay referenced, as a loader's pipeline holds them (see roofline_allhit)
     if world > 1:
         dist.barrier()
@@ -634,7 +633,6 @@ def _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, dev
             # live_outputs: how many delivered tensors stay referenced, as a loader's pipeline holds them.  With none kept, torch's allocator hands the
             # SAME block back for every fetch: the 151 MB of rows written by one launch are still in the 256 MiB Infinity Cache when the next one
             # overwrites them, the writes never reach HBM and the kernel reads 0.80 instead of 0.62-0.65 (profiles/r03_k1_old_vs_new.txt)
-            import collections
             ring = collections.deque(maxlen=max(live_outputs, 1))
             cache.stats(reset=True)
             cache.profile(reset=True)

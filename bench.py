@@ -34,6 +34,117 @@ for _p in (ROOT, PKG):
 # HIP runtime starts; a value already in the environment wins.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
+T_PROCESS_START = time.time()
+# Every watchdog deadline of a run is cut off at T_PROCESS_START + this many seconds, so that a hang ends with the JSON line (with an
+# "error" field) and a non-zero exit code BEFORE a driver's own limit kills the job silently (its limit: 600 s).  --time-budget S or
+# COALA_BENCH_BUDGET_S overrides; extra legs that would not fit into what is left are skipped and say so in the line.
+DEFAULT_BUDGET_S = 420.0
+
+
+def _argv_value(flag, default=None):
+    """`--flag V` / `--flag=V` from sys.argv without argparse (the launcher decision is taken before anything heavy is imported)."""
+    for i, a in enumerate(sys.argv[1:], 1):
+        if a == flag and i + 1 < len(sys.argv):
+            return sys.argv[i + 1]
+        if a.startswith(flag + "="):
+            return a.split("=", 1)[1]
+    return default
+
+
+def _budget_s():
+    try:
+        return float(_argv_value("--time-budget") or os.environ.get("COALA_BENCH_BUDGET_S") or DEFAULT_BUDGET_S)
+    except ValueError:
+        return DEFAULT_BUDGET_S
+
+
+def launch_ranks(n):
+    """`python3 bench.py --gpus N` without a launcher around it: start the N ranks as CHILD processes -- one per GPU, as the reference's
+    launchers do (examples/4GB_script.sh:28-37, examples/sbatch_ssd_gnn_train.py:249-250) -- relay rank 0's JSON line, return the worst
+    exit code.  This process never imports torch and never touches the GPU; nothing is re-executed.  The children get what
+    torch.distributed.run would give them (RANK / LOCAL_RANK / WORLD_SIZE / LOCAL_WORLD_SIZE / MASTER_ADDR / MASTER_PORT)."""
+    import signal
+    import socket
+    import subprocess
+    import threading
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    budget = _budget_s()
+    cpus = len(os.sched_getaffinity(0))
+    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                COALA_BENCH_T0=repr(T_PROCESS_START), COALA_BENCH_BUDGET_S=repr(budget), COALA_BENCH_LAUNCHER_PID=str(os.getpid()))
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    base.setdefault("OMP_NUM_THREADS", str(max(1, min(16, cpus // n))))   # (torch.distributed.run would say 1)
+    cmd = [sys.executable, os.path.abspath(__file__), *sys.argv[1:]]
+    kids = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r), GROUP_RANK="0")
+        # rank 0's stdout comes back through a pipe (the line is relayed and remembered); the other ranks' stdout goes to stderr
+        kids.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0), start_new_session=True))
+    seen = {"line": False}
+
+    def relay():
+        for ln in kids[0].stdout:
+            if ln.startswith("{"):
+                seen["line"] = True
+            sys.stdout.write(ln)
+            sys.stdout.flush()
+    t = threading.Thread(target=relay, daemon=True)
+    t.start()
+
+    def stop_all(sig, *_):
+        for k in kids:
+            if k.poll() is None:
+                try:
+                    os.killpg(k.pid, sig)          # the rank and whatever it started (its own session: start_new_session)
+                except OSError:
+                    pass
+    for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):   # a launcher that is told to stop takes its ranks with it
+        signal.signal(sg, lambda s_, f_: (stop_all(signal.SIGTERM), time.sleep(2.0), stop_all(signal.SIGKILL), os._exit(128 + s_)))
+    # The ranks police themselves (RankGuard: every deadline inside the budget).  This loop is the second line: once one rank has left,
+    # the others get 20 s to follow (they see the failure flag / the missing store), and nobody outlives budget + 45 s.
+    hard_end = T_PROCESS_START + budget + 45.0
+    first_exit = None
+    why = None
+    while any(k.poll() is None for k in kids):
+        now = time.time()
+        if first_exit is None and any(k.poll() is not None for k in kids):
+            first_exit = now
+        if first_exit is not None and now - first_exit > 20.0 and any(k.poll() not in (None, 0) for k in kids):
+            why = "a rank exited with an error and the others did not follow within 20 s"
+        elif first_exit is not None and now - first_exit > 120.0:
+            why = "a rank has finished and the others did not within 120 s"
+        elif now > hard_end:
+            why = f"the ranks were still running {budget + 45.0:.0f} s after the start (time budget {budget:.0f} s)"
+        if why:
+            stop_all(signal.SIGTERM)
+            time.sleep(3.0)
+            stop_all(signal.SIGKILL)
+            break
+        time.sleep(0.2)
+    codes = [k.wait() for k in kids]
+    t.join(timeout=5.0)
+    worst = next((c for c in codes if c != 0), 0)
+    if why and worst == 0:
+        worst = 5
+    if not seen["line"]:   # no rank got as far as printing: the line still appears, with what is known
+        print(json.dumps({"metric": "feature-gather GB/s", "value": None, "unit": "GB/s", "n_gpus": n,
+                          "error": why or f"the ranks exited with codes {codes} before rank 0 printed its line"}), flush=True)
+        worst = worst or 5
+    print(f"[bench] launcher: rank exit codes {codes}" + (f"; {why}" if why else ""), file=sys.stderr, flush=True)
+    return worst
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ and "SLURM_NTASKS" not in os.environ:
+    try:
+        _n_req = int(_argv_value("--gpus", "1"))
+    except ValueError:
+        _n_req = 1
+    if _n_req > 1:
+        sys.exit(launch_ranks(_n_req))
+
 
 def _bind_numa():
     """Before the HIP runtime exists (its helper threads inherit the mask) and before anything is pinned: run this rank on the NUMA
@@ -96,9 +207,9 @@ def parse_args():
                          "cross-rank launch order, which RCCL documents as a deadlock risk and which has never run on two physical GPUs")
     ap.add_argument("--no-epoch-prefetch-multi", dest="epoch_prefetch_multi", action="store_false",
                     help="N>1: serial loader only (the default)")
-    ap.add_argument("--epoch-timeout", type=float, default=240.0,
-                    help="N>1: seconds after which the extra legs are abandoned: the JSON line is printed with an error field and every "
-                         "rank exits with code 3")
+    ap.add_argument("--epoch-timeout", type=float, default=150.0,
+                    help="seconds after which an epoch leg is abandoned (never later than the run's --time-budget): the JSON line is printed "
+                         "with an error field and every rank exits with code 3")
     ap.add_argument("--exchange", type=str, default=None, choices=["torch", "native"],
                     help="N>1: the fused native RCCL call (default whenever the cache group is an RCCL group) or the same sequence "
                          "driven from Python over torch.distributed")
@@ -115,7 +226,20 @@ def parse_args():
                     help="--cold-tier shm: map an EXISTING segment of this name as a non-creator (second mapping of a table another process "
                          "created and filled: tools/shm_two_process_probe.py) instead of creating one")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--time-budget", type=float, default=None,
+                    help=f"seconds, counted from the start of the launcher: every watchdog deadline is cut off there, and extra legs that would "
+                         f"not fit are skipped (default {DEFAULT_BUDGET_S:.0f}, or COALA_BENCH_BUDGET_S): a hang ends with the line + a non-zero code "
+                         f"before a driver's 600 s limit")
     return ap.parse_args()
+
+
+def _maybe_stall(where, rank):
+    """Test hook COALA_BENCH_INJECT_STALL="rank:where": that rank stops making progress at that point (the other ranks then block in
+    their next collective): what a first-contact hang of a transport looks like from outside."""
+    if os.environ.get("COALA_BENCH_INJECT_STALL", "") == f"{rank}:{where}":
+        print(f"[bench] rank {rank}: injected stall at '{where}' (COALA_BENCH_INJECT_STALL)", file=sys.stderr, flush=True)
+        while True:
+            time.sleep(1.0)
 
 
 def log(msg):
@@ -124,35 +248,47 @@ def log(msg):
 
 
 class RankGuard(object):
-    """N>1: keeps a hang or a rank-local failure VISIBLE.  A rank that fails raises a flag in the torch.distributed store and
+    """Keeps a hang or a rank-local failure VISIBLE.  A rank that fails raises a flag in the torch.distributed store and
     exits non-zero; a monitor thread on every rank polls the flag and a deadline, and when either fires rank 0 prints the JSON
     line (with an "error" field and whatever is finished) and every rank leaves with a non-zero code -- ranks blocked inside a
-    collective included.  Nothing is restarted or re-executed: the process just ends, and torch.distributed.run reports failure."""
+    collective included.  Nothing is restarted or re-executed: the process just ends, and the launcher reports failure.
+    Every deadline is cut off at the run's time budget (counted from the start of the launcher, or of this process when there is
+    none): however the legs' individual limits add up, the job has printed its line and left before a driver's own limit."""
     KEY = "coala_bench_failed"
 
-    def __init__(self, rank, world):
+    def __init__(self, rank, world, budget_s=None):
         import threading
         self.rank, self.world = rank, world
         self.line = None          # rank 0: the JSON line as far as it is known
         self.partial = None       # dict of the leg in progress (shown under "epoch" on failure)
         self.deadline, self.what = None, ""
+        self.printed = False      # set once rank 0 has printed the finished line
+        self.t0 = float(os.environ.get("COALA_BENCH_T0", T_PROCESS_START))
+        self.budget_s = float(budget_s if budget_s is not None else _budget_s())
+        self.hard_end = self.t0 + self.budget_s
+        self.launcher_pid = int(os.environ.get("COALA_BENCH_LAUNCHER_PID", "0"))
         # an OWN client connection to the job's rendezvous store: the default store's client is one socket behind one mutex, and
         # a main thread blocked in it (new_group waiting for a rank that has failed) would block this monitor too
         self.store = None
-        if world > 1 and dist.is_initialized():
+        self._stop = threading.Event()
+        self._failing = False
+        self._t = threading.Thread(target=self._watch, daemon=True)   # at N = 1 too: the deadline holds for a single rank as well
+        self._t.start()
+
+    def attach_store(self):
+        """Once the process group exists (the guard itself is armed before: the rendezvous can hang too)."""
+        if self.store is None and self.world > 1 and dist.is_initialized():
             import datetime
             self.store = dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500")),
                                        is_master=False, wait_for_workers=False, timeout=datetime.timedelta(seconds=30))
-        self._stop = threading.Event()
-        self._failing = False
-        self._t = None
-        if self.store is not None:
-            self._t = threading.Thread(target=self._watch, daemon=True)
-            self._t.start()
+
+    def remaining(self):
+        """Seconds of the time budget that are left."""
+        return self.hard_end - time.time()
 
     def arm(self, seconds, what):
         self.what = what
-        self.deadline = time.time() + seconds
+        self.deadline = min(time.time() + seconds, self.hard_end)
 
     def disarm(self):
         self.deadline = None
@@ -161,6 +297,9 @@ class RankGuard(object):
         self._stop.set()
 
     def _leave(self, msg, code):
+        if self.printed:          # the line is out and complete: what hangs now is the teardown, not the measurement
+            print(f"[bench] rank {self.rank}: {msg} -- after the line was printed; leaving", file=sys.stderr, flush=True)
+            os._exit(0)
         if self.rank != 0:
             time.sleep(2.0)       # rank 0 prints the line first: the launcher tears every rank down as soon as one has exited
         if self.rank == 0:
@@ -176,13 +315,17 @@ class RankGuard(object):
         while not self._stop.wait(0.5):
             if self._failing:
                 return            # fail() on the main thread does the leaving
-            try:
-                if self.store.check([self.KEY]):
-                    self._leave("a rank failed: " + self.store.get(self.KEY).decode(errors="replace"), 4)
-            except Exception:  # noqa: BLE001 -- the store went away with rank 0: nothing left to wait for
-                self._leave("the rendezvous store is gone (rank 0 left)", 4)
+            if self.store is not None:
+                try:
+                    if self.store.check([self.KEY]):
+                        self._leave("a rank failed: " + self.store.get(self.KEY).decode(errors="replace"), 4)
+                except Exception:  # noqa: BLE001 -- the store went away with rank 0: nothing left to wait for
+                    self._leave("the rendezvous store is gone (rank 0 left)", 4)
+            if self.launcher_pid and os.getppid() != self.launcher_pid:
+                self._leave("the launcher process is gone", 4)
             if self.deadline is not None and time.time() > self.deadline:
-                self._leave(f"{self.what} abandoned by the watchdog (no completion within its time limit)", 3)
+                cut = " (the run's time budget of %.0f s)" % self.budget_s if self.deadline >= self.hard_end - 1e-3 else ""
+                self._leave(f"{self.what} abandoned by the watchdog (no completion within its time limit{cut})", 3)
 
     def fail(self, exc):
         """Called by the rank that caught an exception: tell the others, then leave non-zero."""
@@ -202,9 +345,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if world != args.gpus:   # (`python3 bench.py --gpus N` with no WORLD_SIZE never gets here: launch_ranks() above starts the N ranks)
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -248,11 +389,13 @@ def main():
             args.exchange = "native"
         os.environ["COALA_EXCHANGE"] = args.exchange      # the managers of the later legs (loader, fan-out 10,10) follow
     args.rehearsal = rehearsal
+    guard = RankGuard(rank, world, args.time_budget)
+    guard.arm(180.0, "process-group set-up")
     comm = MPI_Comm_Manager(0, backend="gloo" if single_dev else None)   # one machine: every rank in domain 0
     comm.device_index = dev_index
     comm.initialize_nested_process_group(backend)
-    guard = RankGuard(rank, world)
-    guard.arm(1500.0, "setup + timed region")
+    guard.attach_store()
+    guard.arm(300.0, "cold tier + graph set-up")
     try:
         _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, device, backend, comm, guard)
     except SystemExit:
@@ -403,38 +546,51 @@ def _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, dev
         torch.cuda.synchronize()
         return bool(torch.equal(got, feature_rows_torch(b[0], args.dim, args.seed)))
 
+    # Test hook COALA_BENCH_INJECT_EXCHANGE_FAIL="<rank>": that rank reports its first minibatch over the FIRST exchange as wrong (the
+    # exchange itself has run, on real objects), so that the fall-back below is executed: every rank drops its manager -- a native
+    # exchange's communicator is destroyed -- and continues over the torch transport, and the line says so.
+    inject_xfail = os.environ.get("COALA_BENCH_INJECT_EXCHANGE_FAIL", "") == str(rank)
+    multi = world > 1 or args.rehearsal        # a one-rank rehearsal walks the same fall-back (its RCCL communicators are real)
+
     # N>1: the fused native exchange over RCCL has never seen two physical GPUs before the driver's run.  If it raises or delivers a
     # wrong row on ANY rank, every rank falls back to the torch.distributed transport (same sequence, driven from Python) with
     # sampler-order ids, and the line says so.  (A hang cannot be recovered in-process: the RankGuard ends the job non-zero.)
     exchange_note = None
     manager = None
-    if world > 1:
-        guard.arm(240.0, "communicator set-up + first minibatch over the exchange")
+    guard.arm(180.0, "communicator set-up + first minibatch over the exchange")
+    _maybe_stall("first_fetch", rank)
     try:
         manager = make_manager(args.exchange)
-        ok = first_fetch_is_exact(manager, sampler) if (world > 1 and args.mode == "minibatch") else True
+        ok = first_fetch_is_exact(manager, sampler) if (multi and args.mode == "minibatch") else True
         err = None if ok else "the first minibatch differs from the table"
+        if ok and inject_xfail:
+            ok, err = False, "injected (COALA_BENCH_INJECT_EXCHANGE_FAIL)"
     except Exception as e:  # noqa: BLE001
-        if world == 1:
+        if not multi:
             raise
         ok, err = False, repr(e)
-    if world > 1:
+    if multi:
         flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=comm.local_gloo_gather)   # a CPU group: usable whatever state RCCL is in
+        if world > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=comm.local_gloo_gather)   # a CPU group: usable whatever state RCCL is in
         if int(flag[0]) == 0:
             kind = getattr(manager, "exchange_kind", args.exchange or "native")
             log(f"exchange '{kind}' failed its first-minibatch check on at least one rank ({err}): falling back to the torch transport")
-            if kind == "torch":
+            injected = os.environ.get("COALA_BENCH_INJECT_EXCHANGE_FAIL") is not None
+            if kind == "torch" and not injected:
                 raise RuntimeError(f"parity self-check failed with the torch transport on rank {rank}: {err}")
-            exchange_note = f"torch (fallback: the native exchange failed its first-minibatch check: {err})"
+            exchange_note = f"torch (fallback: the {kind} exchange failed its first-minibatch check on at least one rank" + (f": {err})" if err else ")")
+            if manager is not None and getattr(manager, "exchange", None) is not None and hasattr(manager.exchange, "close"):
+                manager.exchange.close()               # a native exchange: its RCCL communicator goes now, not at some later collection
             manager = None
             bucket = 0
             os.environ["COALA_EXCHANGE"] = "torch"     # the managers of the later legs (epoch, fan-out 10,10) follow
+            args.exchange = "torch"
             sampler = NeighborSampler(fanout, seed=args.seed)
             manager = make_manager("torch")
             if not first_fetch_is_exact(manager, sampler):
                 raise RuntimeError(f"parity self-check failed on rank {rank} with the torch transport as well")
-    guard.arm(1500.0, "prewarm + timed region")
+    guard.arm(300.0, "prewarm + timed region")
     cache = manager.COALA_GNN_Cache
     max_rows = manager.max_sample_size
     manager.sync_on_return = False  # stream-ordered fetches: the timed region is bracketed by synchronisations below
@@ -751,7 +907,24 @@ def _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, dev
     # They run last and never cost the headline number silently: at N>1 a rank-local exception or a stall ends the whole job
     # with a non-zero exit code, after rank 0 has printed the line with an "error" field (RankGuard).
     guard.line = line
-    if args.mode == "minibatch" and args.epoch_steps != 0:
+
+    def leg_fits(name, need_s):
+        """An extra leg runs only if what is left of the time budget covers it -- the same decision on every rank; a skipped leg says so."""
+        left = guard.remaining()
+        ok = left >= need_s
+        if world > 1:
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=comm.local_gloo_gather)
+            ok = bool(int(t[0]))
+        if not ok:
+            log(f"{name} skipped: {left:.0f} s of the {guard.budget_s:.0f} s time budget left, {need_s:.0f} s wanted")
+        return ok, {"skipped": f"{left:.0f} s of the run's {guard.budget_s:.0f} s time budget were left, this leg wants {need_s:.0f} s (--time-budget)"}
+
+    _maybe_stall("extra_legs", rank)
+    fits, skipped = leg_fits("epoch leg", 75.0) if (args.mode == "minibatch" and args.epoch_steps != 0) else (False, None)
+    if skipped is not None and not fits and rank == 0:
+        line["epoch"] = skipped
+    if fits:
         partial = {}
         guard.partial = partial
         guard.arm(args.epoch_timeout, "epoch leg")
@@ -765,21 +938,26 @@ def _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, dev
     # same table / graph / cache size, at EVERY N (so that its per-N curve has an origin at N = 1), next to the weak-scaling
     # `value` above, which keeps the N = 1 fan-out so that the driver's per-N values stay comparable
     if args.mode == "minibatch" and args.fanout == "5,5" and not args.no_fanout_leg:
-        guard.arm(args.epoch_timeout, "fan-out 10,10 leg")
-        extra = run_fanout_leg(args, comm, graph, table, device, [10, 10], backend, cold_partitioned, world, rank, train_ids,
-                               steps_per_epoch, single_dev)
+        fits, skipped = leg_fits("fan-out 10,10 leg", 30.0)
+        if fits:
+            guard.arm(120.0, "fan-out 10,10 leg")
+            skipped = run_fanout_leg(args, comm, graph, table, device, [10, 10], backend, cold_partitioned, world, rank, train_ids,
+                                     steps_per_epoch, single_dev)
         if rank == 0:
-            line["config_fanout_10_10"] = extra
+            line["config_fanout_10_10"] = skipped
     # N=1 only: the reference's distribution comparison (examples/Distribution_compare_script.sh:26-34) on one box -- two domains
     # x 1 rank on this GPU, real colours from the native colouring tool, node_color against baseline.  A child process: a failure
     # there is reported in the object and never costs the line.
     if world == 1 and args.mode == "minibatch" and not args.no_color_affinity_leg:
-        line["color_affinity"] = run_color_affinity_leg()
+        fits, skipped = leg_fits("colour-affinity leg", 60.0)
+        guard.disarm()     # (a child process with a timeout of its own, inside what is left of the budget)
+        line["color_affinity"] = run_color_affinity_leg(timeout_s=max(30.0, min(400.0, guard.remaining() - 15.0))) if fits else skipped
     guard.disarm()
     if rank == 0:
         print(json.dumps(line), flush=True)
+    guard.printed = True
     if world > 1:
-        guard.arm(120.0, "teardown")
+        guard.arm(60.0, "teardown")
         dist.barrier()
     del manager
     if world > 1:

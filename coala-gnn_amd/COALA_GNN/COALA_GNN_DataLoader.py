@@ -135,7 +135,7 @@ class SSD_INFO(object):  # COALA_GNN_DataLoader.py:80-90
 class COALA_GNN_DataLoader(torch.utils.data.DataLoader):
     def __init__(self, SSD_info, node_distributor, graph, graph_sampler, batch_size, dim, fan_out, cache_size, device,
                  refresh_counter=10, cache_backend="nvshmem", sim_buf=None, shuffle=False, num_rows=None, profile=False,
-                 prefetch=0, cold_partitioned=False, sync_fetch=False, counts_ahead=None):
+                 prefetch=0, cold_partitioned=False, sync_fetch=False, counts_ahead=None, fetch_depth=1):
         # like the reference, torch's DataLoader.__init__ is never called: this is a plain iterator
         # prefetch = 0: the reference's strictly serial __next__ (:149-167).  prefetch = k > 0: a producer thread runs
         # distribute -> sample -> fetch for the next k steps on its own HIP stream while the consumer trains (SURVEY f-2).
@@ -147,15 +147,18 @@ class COALA_GNN_DataLoader(torch.utils.data.DataLoader):
         # synchronisation (coala_comm_counts_begin).  A fetch whose ticket has left the communicator's ring of pending count
         # exchanges falls back to the synchronous count (NativeExchange.fetch_bucketed) -- every rank makes the same calls in the same
         # order, so every rank falls back together.  Every rank of the cache group must use the same setting.
+        # fetch_depth (one-thread pipeline, prefetch = 0): how many fetches are kept enqueued on the fetch stream beyond the step being
+        # handed over (1: the fetch of step t+1 is enqueued when step t is handed over; the sampler runs one step further ahead).
         self.counts_ahead = counts_ahead
+        self.fetch_depth = max(1, int(fetch_depth))
         self.prefetch = int(prefetch)
         self._producer = None
         self._queue = None
         self._side_stream = None
         self._sample_stream = None
         self._stop = threading.Event()   # set by close(): the producer gives up at its next queue hand-off
-        self._ahead = None               # serial mode: the sample two steps ahead, already enqueued (see _produce_one)
-        self._ready = None               # serial mode: the fetch one step ahead, already enqueued
+        self._samples = collections.deque()   # serial mode: samples launched and not yet fetched (see _produce_one)
+        self._fetched = collections.deque()   # serial mode: fetches enqueued and not yet handed over
         self._sampled = 0                # samples launched this epoch
         self.producer_times = {"schedule": 0.0, "sample": 0.0, "fetch": 0.0, "queue_full": 0.0, "gpu_backlog": 0.0}
         self.refresh_counter = refresh_counter
@@ -217,8 +220,7 @@ class COALA_GNN_DataLoader(torch.utils.data.DataLoader):
 
     def _enqueue_fetch(self):
         """The sample launched earlier -> its fetch ENQUEUED on the fetch stream; -> (item, event that marks its rows complete)."""
-        pending, ev_s, ticket = self._ahead
-        self._ahead = None
+        pending, ev_s, ticket = self._samples.popleft()
         batch = self.sampler.sample_end(pending)  # counts of a sample enqueued a whole step ago: no wait in steady state
         if ticket is not None:
             batch[2][0].counts_ticket = ticket
@@ -243,17 +245,10 @@ class COALA_GNN_DataLoader(torch.utils.data.DataLoader):
             # the colour snapshot stays ordered behind the same fetch as in the serial sequence.)
             if self._side_stream is None:
                 self._side_stream, self._sample_stream = _loader_streams(self.device)
-            if self._ready is None:  # first call of an epoch: fill the pipeline
-                self._ahead = self._launch_sample()
-                self._ready = self._enqueue_fetch()
-                if self._sampled < self.total_count:
-                    self._ahead = self._launch_sample()
-            item, ev = self._ready
-            self._ready = None
-            if self._ahead is not None:
-                self._ready = self._enqueue_fetch()
-                if self._sampled < self.total_count:
-                    self._ahead = self._launch_sample()
+            if not self._fetched:  # first call of an epoch: fill the pipeline
+                self._pump()
+            item, ev = self._fetched.popleft()
+            self._pump()
             cur = torch.cuda.current_stream()
             cur.wait_event(ev)  # the consumer's stream sees the finished rows
             for t in _device_tensors(item):
@@ -265,9 +260,21 @@ class COALA_GNN_DataLoader(torch.utils.data.DataLoader):
         self.counter += 1
         return self.COALA_GNN_Manager.fetch_feature(batch)
 
+    def _pump(self):
+        """Keep fetch_depth fetches enqueued and one sample launched beyond the last of them (same order of calls as ever: fetch t+1,
+        then sample t+2)."""
+        while len(self._fetched) < self.fetch_depth:
+            if not self._samples:
+                if self._sampled >= self.total_count:
+                    break
+                self._samples.append(self._launch_sample())
+            self._fetched.append(self._enqueue_fetch())
+        if not self._samples and self._sampled < self.total_count:
+            self._samples.append(self._launch_sample())
+
     def _end_of_epoch(self):
-        self._ahead = None
-        self._ready = None
+        self._samples.clear()
+        self._fetched.clear()
         self._sampled = 0
         self.scheduler.drain()  # the reference resets while a distributor thread may still run (SURVEY A.13)
         self.node_distributor.reset()
@@ -359,7 +366,7 @@ class COALA_GNN_DataLoader(torch.utils.data.DataLoader):
 
     def __next__(self):  # COALA_GNN_DataLoader.py:149-167
         if self.prefetch <= 0:
-            if self.counter >= self.total_count and self._ready is None:
+            if self.counter >= self.total_count and not self._fetched:
                 self._end_of_epoch()
                 raise StopIteration
             return self._produce_one()

@@ -309,6 +309,10 @@ class NativeExchange(object):
     def rounds(self, k):  # must be set to the same value on every rank, between fetches
         self._capi.check(self._lib.coala_comm_set_rounds(self._h, int(k)))
 
+    def set_self_loopback(self, on):
+        """Diagnostics (coala_comm_set_self_loopback): the own segment takes the road of a peer's, through the transport itself."""
+        self._capi.check(self._lib.coala_comm_set_self_loopback(self._h, 1 if on else 0))
+
     # same profiling surface as AllToAllExchange (bench.py's xGMI figure)
     @property
     def profile(self):

@@ -46,6 +46,8 @@ constexpr int kMaxRounds = 8;
 
 struct Transport {
     int rank = 0, nranks = 1;
+    // coala_comm_set_self_loopback: a rank's OWN segment goes through the transport's send/recv path like a peer's (diagnostics)
+    bool self_loopback = false;
     virtual ~Transport() {}
     // recv[p] = element [me] of rank p's send (one int64 per peer, self included)
     virtual int all_to_all_i64(const int64_t* send_dev, int64_t* recv_dev, hipStream_t st) = 0;
@@ -72,12 +74,13 @@ struct RcclTransport : Transport {
                      size_t elem_bytes, bool include_self, hipStream_t st) override {
         const ncclDataType_t dt = (elem_bytes % 8 == 0) ? ncclInt64 : ncclFloat32;
         const size_t per = (elem_bytes % 8 == 0) ? elem_bytes / 8 : elem_bytes / 4;
-        if (include_self && scnt[rank])
+        const bool self_by_rccl = include_self && self_loopback; // ncclSend + ncclRecv to oneself inside the group call: legal, and a local copy inside RCCL
+        if (include_self && scnt[rank] && !self_by_rccl)
             HIPCHK(hipMemcpyAsync((char*)recv + rdis[rank] * elem_bytes, (const char*)send + sdis[rank] * elem_bytes, scnt[rank] * elem_bytes,
                                   hipMemcpyDeviceToDevice, st));
         NCCLCHK(ncclGroupStart());
         for (int p = 0; p < nranks; ++p) {
-            if (p == rank) continue;
+            if (p == rank && !self_by_rccl) continue;
             if (scnt[p]) NCCLCHK(ncclSend((const char*)send + sdis[p] * elem_bytes, scnt[p] * per, dt, p, comm, st));
             if (rcnt[p]) NCCLCHK(ncclRecv((char*)recv + rdis[p] * elem_bytes, rcnt[p] * per, dt, p, comm, st));
         }
@@ -113,8 +116,12 @@ struct coala_comm_group {
         const size_t* scnt = nullptr;
         const size_t* sdis = nullptr;
         hipEvent_t ready = nullptr, done = nullptr;
+        int device = -1; // the device this rank's buffers live on
     };
     std::vector<Slot> slot;
+    // peer_state[a * 64 + b]: may a kernel on device a read device b's memory?  0 unknown, 1 yes (same device, or peer access
+    // enabled and verified), 2 no (the runtime's copy engine moves the segment instead)
+    std::vector<unsigned char> peer_state = std::vector<unsigned char>(64 * 64, 0);
 
     int barrier() { // -> 0, or -1 when the group was aborted
         std::unique_lock<std::mutex> lk(m);
@@ -157,9 +164,11 @@ __global__ __launch_bounds__(256) void inproc_copy_kernel(char* __restrict__ dst
     }
 }
 
-int inproc_copy(void* dst, const void* src, size_t bytes, hipStream_t st) {
-    if (bytes < (64u << 10)) { // small segments (ids, counts): the runtime's copy is fine
-        HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st));
+// kernel_ok: the source is on this device, or on a peer whose memory this device has mapped (peer_readable below).  Otherwise --
+// and for small segments (ids, counts) -- the runtime's copy, which needs no peer mapping.
+int inproc_copy(void* dst, const void* src, size_t bytes, hipStream_t st, bool kernel_ok) {
+    if (bytes < (64u << 10) || !kernel_ok) {
+        HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, st));
         return COALA_OK;
     }
     const size_t blocks = (bytes / 16 + 256 * 8 - 1) / (256 * 8);
@@ -168,8 +177,28 @@ int inproc_copy(void* dst, const void* src, size_t bytes, hipStream_t st) {
     return COALA_OK;
 }
 
+// May a kernel running on device `mine` read memory of device `theirs`?  Decided once per ordered pair (under the group's mutex):
+// hipDeviceCanAccessPeer + hipDeviceEnablePeerAccess; a pair without peer access is served by hipMemcpyAsync.
+bool peer_readable(coala_comm_group* g, int mine, int theirs) {
+    if (mine == theirs) return true;
+    if (mine < 0 || theirs < 0 || mine >= 64 || theirs >= 64) return false;
+    std::lock_guard<std::mutex> lk(g->m);
+    unsigned char& st = g->peer_state[(size_t)mine * 64 + theirs];
+    if (st == 0) {
+        int can = 0;
+        st = 2;
+        if (hipDeviceCanAccessPeer(&can, mine, theirs) == hipSuccess && can) {
+            const hipError_t e = hipDeviceEnablePeerAccess(theirs, 0); // (the calling thread's current device is `mine`)
+            if (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) st = 1;
+        }
+        (void)hipGetLastError();
+    }
+    return st == 1;
+}
+
 struct InprocTransport : Transport {
     coala_comm_group* g = nullptr;
+    int device = -1;
     int exchange(const void* send, const size_t* scnt, const size_t* sdis, void* recv, const size_t* rcnt, const size_t* rdis,
                  size_t elem_bytes, bool include_self, hipStream_t st) {
         auto& me = g->slot[rank];
@@ -187,7 +216,9 @@ struct InprocTransport : Transport {
             }
             if (!rcnt[p]) continue;
             if (p != rank) HIPCHK(hipStreamWaitEvent(st, peer.ready, 0));
-            if (int rc = inproc_copy((char*)recv + rdis[p] * elem_bytes, (const char*)peer.send + peer.sdis[rank] * elem_bytes, rcnt[p] * elem_bytes, st)) return rc;
+            if (int rc = inproc_copy((char*)recv + rdis[p] * elem_bytes, (const char*)peer.send + peer.sdis[rank] * elem_bytes, rcnt[p] * elem_bytes, st,
+                                     peer_readable(g, device, peer.device)))
+                return rc;
         }
         HIPCHK(hipEventRecord(me.done, st)); // I have pulled what I need from everybody
         if (g->barrier()) return fail(COALA_ECOMM, "in-process group aborted (a peer failed or did not arrive in time)");
@@ -252,6 +283,7 @@ struct coala_comm {
     std::vector<hipEvent_t> prof_pool;
     coala_comm_profile_t prof{};
     bool broken = false;
+    bool loopback = false;          // coala_comm_set_self_loopback
     // count exchanges issued ahead of their fetch (coala_comm_counts_begin): ring of device [2G] + pinned [2G] + event
     static constexpr int kCountsRing = COALA_COUNTS_RING;
     int64_t* ahead_dev = nullptr;   // [kCountsRing][2G]
@@ -424,7 +456,9 @@ int coala_comm_create_inproc(coala_comm_group_t* g, int rank, int device, coala_
     t->g = g;
     t->rank = rank;
     t->nranks = g->nranks;
+    t->device = device;
     auto& sl = g->slot[rank];
+    sl.device = device;
     if (sl.ready || hipEventCreateWithFlags(&sl.ready, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess) {
         delete c;
@@ -484,6 +518,13 @@ int coala_comm_set_rounds(coala_comm_t* c, int rounds) {
 }
 
 int coala_comm_get_rounds(const coala_comm_t* c) { return c ? c->rounds : 0; }
+
+int coala_comm_set_self_loopback(coala_comm_t* c, int on) {
+    if (!c || !c->tr) return fail(COALA_EINVAL, "null communicator");
+    c->loopback = on != 0;
+    c->tr->self_loopback = c->loopback;
+    return COALA_OK;
+}
 
 int coala_comm_last_counts(const coala_comm_t* c, int64_t* send, int64_t* recv) {
     if (!c) return fail(COALA_EINVAL, "null communicator");
@@ -639,20 +680,24 @@ static int fetch_impl(coala_cache_t* h, coala_comm_t* c, float* out, const int64
         return broke(rc);
     // 5. owner side: ONE batch = the concatenation in source-rank order (DESIGN.md "Determinism contract").  Probe all of it;
     //    the own segment is delivered straight to out[map[..]] -- it never sees rows_send, the exchange or rows_recv.
+    //    (self-loopback, diagnostics: no own-shard bypass -- the own segment is served, shipped and un-permuted like a peer's, so that a
+    //    communicator of ONE rank drives every line of the row exchange below through the transport)
+    const bool loop = c->loopback;
     coala_row_redirect_t rd;
     rd.begin = (int64_t)rdis[me];
-    rd.end = (int64_t)(rdis[me] + rcnt[me]);
+    rd.end = loop ? rd.begin : (int64_t)(rdis[me] + rcnt[me]);
     rd.out = bucketed ? out + sdis[me] * (size_t)dim : out; // bucketed: the own bucket sits at its offset, in order
     rd.row_map = bucketed ? nullptr : c->map + sdis[me];
     if ((rc = coala_cache_serve_probe_redirect(h, c->rows_send, c->recv_ids, (int64_t)total_recv, &rd, st))) return broke(rc);
     // 6. rounds: fill slice k of every peer's segment on the caller's stream, ship it on the comm stream while slice k+1 fills
-    const int K = (G == 1) ? 1 : c->rounds;
+    const int K = (G == 1 && !loop) ? 1 : c->rounds;
+    const bool exchange_rows = G > 1 || loop;
     const size_t row_bytes = (size_t)dim * sizeof(float);
     std::vector<int64_t> fb(G), fe(G);
     std::vector<size_t> xs_cnt(G), xs_dis(G), xr_cnt(G), xr_dis(G);
     std::vector<int64_t> sb((size_t)G * K), se((size_t)G * K); // requester-side ranges of rows_recv, per round
     hipEvent_t t0 = nullptr, t1 = nullptr;
-    if (c->profile && G > 1) {
+    if (c->profile && exchange_rows) {
         if (c->prof_live.size() >= 4096) drain_profile(c);
         t0 = take_timing_event(c);
         t1 = take_timing_event(c);
@@ -661,7 +706,7 @@ static int fetch_impl(coala_cache_t* h, coala_comm_t* c, float* out, const int64
         int nr = 0;
         for (int p = 0; p < G; ++p) {
             int64_t b, e;
-            if (p == me) { // own segment: nobody waits for it on a link -> last round
+            if (p == me && !loop) { // own segment: nobody waits for it on a link -> last round
                 if (k != K - 1) continue;
                 b = (int64_t)rdis[p];
                 e = (int64_t)(rdis[p] + rcnt[p]);
@@ -672,26 +717,27 @@ static int fetch_impl(coala_cache_t* h, coala_comm_t* c, float* out, const int64
             if (e > b) { fb[nr] = b; fe[nr] = e; ++nr; }
         }
         if ((rc = coala_cache_serve_fill_ranges(h, c->rows_send, c->recv_ids, (int64_t)total_recv, fb.data(), fe.data(), nr, st))) return broke(rc);
-        if (G > 1 && hipEventRecord(c->ev_fill[k], st) != hipSuccess) return broke(fail(COALA_EHIP, "hipEventRecord failed"));
+        if (exchange_rows && hipEventRecord(c->ev_fill[k], st) != hipSuccess) return broke(fail(COALA_EHIP, "hipEventRecord failed"));
     }
-    if (total_recv == 0 && G > 1) // nothing to serve: the rounds below still run (peers may owe this rank rows)
+    if (total_recv == 0 && exchange_rows) // nothing to serve: the rounds below still run (peers may owe this rank rows)
         for (int k = 0; k < K; ++k)
             if (hipEventRecord(c->ev_fill[k], st) != hipSuccess) return broke(fail(COALA_EHIP, "hipEventRecord failed"));
-    if (G > 1) {
+    if (exchange_rows) {
         for (int k = 0; k < K; ++k) {
             for (int p = 0; p < G; ++p) {
                 const size_t a = rcnt[p] * (size_t)k / (size_t)K, b = rcnt[p] * (size_t)(k + 1) / (size_t)K;     // what I serve to p
                 const size_t u = scnt[p] * (size_t)k / (size_t)K, v = scnt[p] * (size_t)(k + 1) / (size_t)K;     // what p serves to me
-                xs_cnt[p] = (p == me) ? 0 : b - a;
+                const bool skip = p == me && !loop;
+                xs_cnt[p] = skip ? 0 : b - a;
                 xs_dis[p] = rdis[p] + a;
-                xr_cnt[p] = (p == me) ? 0 : v - u;
+                xr_cnt[p] = skip ? 0 : v - u;
                 xr_dis[p] = sdis[p] + u;
                 sb[(size_t)k * G + p] = (int64_t)(sdis[p] + u);
-                se[(size_t)k * G + p] = (p == me) ? (int64_t)(sdis[p] + u) : (int64_t)(sdis[p] + v);
+                se[(size_t)k * G + p] = skip ? (int64_t)(sdis[p] + u) : (int64_t)(sdis[p] + v);
             }
             if (hipStreamWaitEvent(c->cs, c->ev_fill[k], 0) != hipSuccess) return broke(fail(COALA_EHIP, "hipStreamWaitEvent failed"));
             if (k == 0 && t0) (void)hipEventRecord(t0, c->cs);
-            if ((rc = c->tr->all_to_all_v(c->rows_send, xs_cnt.data(), xs_dis.data(), rows_recv, xr_cnt.data(), xr_dis.data(), row_bytes, false, c->cs)))
+            if ((rc = c->tr->all_to_all_v(c->rows_send, xs_cnt.data(), xs_dis.data(), rows_recv, xr_cnt.data(), xr_dis.data(), row_bytes, loop, c->cs)))
                 return broke(rc);
             if (hipEventRecord(c->ev_x[k], c->cs) != hipSuccess) return broke(fail(COALA_EHIP, "hipEventRecord failed"));
         }

@@ -98,7 +98,7 @@ inline bool is_space(char c) { return c == ' ' || c == '\t' || c == '\n' || c ==
 extern "C" {
 
 const char* coala_last_error(void) { return g_err; }
-int coala_abi_version(void) { return 3; }
+int coala_abi_version(void) { return 4; }
 
 // ------------------------------------------------------------------------------------------------ shm
 int coala_shm_open(const char* name, uint64_t bytes, int is_creator, int device, coala_shm_t** out) {

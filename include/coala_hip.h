@@ -176,8 +176,9 @@ int coala_comm_destroy(coala_comm_t* c);
  * at creation), the group size for the in-process transport.  Negative on failure. */
 int coala_comm_size(const coala_comm_t* c);
 /* In-process transport: the nranks ranks of a group are host THREADS of one process (one communicator each, any mix of
- * devices with peer access, several ranks per device allowed); ids and rows move with device-to-device copies ordered by
- * events.  Same orchestration as over RCCL -- it is how the parity tests run G logical ranks on one GPU, and how a
+ * devices, several ranks per device allowed); ids and rows move with device-to-device copies ordered by events -- a copy kernel
+ * on the receiver's device when the sender's memory is on the same device or on a peer whose access could be enabled
+ * (hipDeviceCanAccessPeer / hipDeviceEnablePeerAccess, once per device pair), the runtime's hipMemcpyAsync otherwise.  Same orchestration as over RCCL -- it is how the parity tests run G logical ranks on one GPU, and how a
  * single-process multi-GPU driver would use the partitioned cache.  The group outlives its communicators. */
 typedef struct coala_comm_group coala_comm_group_t;
 int coala_comm_group_create(int nranks, coala_comm_group_t** out);
@@ -187,6 +188,12 @@ int coala_comm_create_inproc(coala_comm_group_t* g, int rank, int device, coala_
  * segment while the cold fill of slice k+1 runs.  Must be the same on every rank. */
 int coala_comm_set_rounds(coala_comm_t* c, int rounds);
 int coala_comm_get_rounds(const coala_comm_t* c); /* 0 for a null handle */
+/* Diagnostics (off by default; the same setting on every rank): with on != 0 a rank's OWN segment takes the road of a peer's -- no
+ * own-shard bypass, its rows are served into the staging buffer, shipped in rounds on the communicator's stream and un-permuted, and
+ * the RCCL transport moves it with ncclSend + ncclRecv to ITSELF inside the same group call as the peers' segments instead of a local
+ * copy.  Delivered rows and cache state are the same.  It exists so that a communicator of one rank -- all a one-GPU box can create
+ * over RCCL -- executes every line of the exchange (counts, datatypes, displacements, both streams) on the real transport. */
+int coala_comm_set_self_loopback(coala_comm_t* c, int on);
 /* per-peer id counts of the last fetch (host int64[nranks] each, either may be NULL) */
 int coala_comm_last_counts(const coala_comm_t* c, int64_t* send, int64_t* recv);
 /* out[i, 0:dim] = row of idx[i], wherever its owner (idx[i] % nranks) is.  Collective: every rank of the communicator calls

@@ -24,7 +24,7 @@ def test_header_symbols_are_exported_and_bound(hiplib):
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} is declared in include/coala_hip.h but not exported by libcoala_hip.so"
     assert declared == set(_capi.SYMBOLS), f"ctypes table out of sync: {declared ^ set(_capi.SYMBOLS)}"
-    assert _capi.load().coala_abi_version() == 3
+    assert _capi.load().coala_abi_version() == 4
 
 
 def test_geometry_matches_reference_rules(hiplib, oracle):

@@ -66,6 +66,69 @@ def test_bench_two_ranks_on_one_gpu_with_epoch_leg():
     assert rp["chosen"] in (1, 2, 4) and set(rp["ms_per_fetch"]) == {"1", "2", "4"} and all(v > 0 for v in rp["ms_per_fetch"].values())
 
 
+def test_bench_self_launch_two_ranks():
+    """`python3 bench.py --gpus 2` with NO launcher around it (the form a driver uses at N = 1): bench.py starts its two ranks as child
+    processes before anything touches the GPU, relays rank 0's line and returns the worst exit code (examples/4GB_script.sh:28-37: one
+    process per GPU, started by the launcher)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["COALA_BENCH_SINGLE_DEVICE"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", *SMALL, "--no-fanout-leg"], capture_output=True, text=True,
+                         timeout=900, env=env)
+    d = _line(out)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "error" not in d and d["config"]["TEST_HOOK_single_device"] is True
+    assert d["epoch"]["serial"]["steps"] == 12
+    assert "launcher: rank exit codes [0, 0]" in out.stderr
+
+
+def test_bench_stall_ends_inside_the_time_budget():
+    """A rank that stops making progress (what a first-contact hang of a transport looks like): every watchdog deadline is cut off at the
+    run's time budget, so the job prints its line with an "error" field and leaves non-zero well before a driver's own limit."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(COALA_BENCH_SINGLE_DEVICE="1", COALA_BENCH_INJECT_STALL="1:first_fetch")
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", *SMALL, "--time-budget", "75"], capture_output=True,
+                         text=True, timeout=600, env=env)
+    took = time.time() - t0
+    assert out.returncode != 0 and took < 75 + 45, (out.returncode, took)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-1500:] + out.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert "abandoned by the watchdog" in d["error"] and "time budget" in d["error"]
+
+
+def test_bench_extra_legs_are_skipped_when_the_budget_is_short():
+    """With little of the time budget left the extra legs are skipped and say so; the headline line still comes out with code 0."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *SMALL, "--time-budget", "74", "--no-cpu-baseline", "--no-allhit"],
+                         capture_output=True, text=True, timeout=600)
+    d = _line(out)
+    assert d["value"] > 0 and "skipped" in d["epoch"] and "error" not in d
+
+
+def test_bench_fallback_to_torch_transport_two_ranks():
+    """The first-minibatch check fails on ONE rank (injected): every rank must agree (flag over the CPU group), drop its exchange and go
+    on over the torch transport, and the line says so (COALA_GNN_Manager.py:159-203 is what the fall-back re-creates in Python)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(COALA_BENCH_SINGLE_DEVICE="1", COALA_BENCH_INJECT_EXCHANGE_FAIL="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", *SMALL, "--no-fanout-leg", "--epoch-steps", "0"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    d = _line(out)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["exchange_transport"].startswith("torch (fallback")
+    assert d["config"]["input_nodes"] == "sampler order"
+
+
+def test_bench_fallback_from_native_rccl_exchange_one_rank():
+    """The same fall-back from the NATIVE exchange on real RCCL objects (one-rank rehearsal): the native exchange runs its first minibatch,
+    is declared failed (injected), its RCCL communicator is destroyed, and the run continues over torch's communicator."""
+    env = dict(os.environ, COALA_BENCH_INJECT_EXCHANGE_FAIL="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *SMALL, "--backend", "nccl", "--no-fanout-leg", "--epoch-steps", "0"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    d = _line(out)
+    c = d["config"]
+    assert c["rccl_rehearsal_one_rank"] is True and c["exchange_transport"].startswith("torch (fallback: the native exchange")
+    assert d["value"] > 0 and c["counts_ahead"] is False
+
+
 def test_bench_one_rank_rccl_rehearsal():
     """`bench.py --backend nccl` at N = 1: a torch.distributed world of one rank with RCCL for GPU tensors, the fused native exchange on
     its OWN one-rank RCCL communicator (ranks as ncclCommCount reports them), sampler-bucketed ids, count exchanges issued ahead, and

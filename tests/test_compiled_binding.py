@@ -26,7 +26,7 @@ REFERENCE_METHODS = {
 def test_compiled_module_has_the_reference_surface(hiplib):
     nat = hiplib.native
     assert nat is not None, "the compiled binding was not built (coala-gnn_amd/build.py builds it)"
-    assert nat.abi_version() == 3
+    assert nat.abi_version() == 4
     assert REFERENCE_CLASSES <= set(dir(nat))
     for cls, methods in REFERENCE_METHODS.items():
         assert methods <= set(dir(getattr(nat, cls))), f"{cls} lacks {methods - set(dir(getattr(nat, cls)))}"

@@ -646,6 +646,126 @@ def test_counts_ahead_ticket_ring_exhaustion_falls_back(hiplib, oracle):
         t.close()
 
 
+@pytest.mark.parametrize("dim,rounds,bucketed", [(100, 2, False), (99, 2, False), (1024, 3, False), (128, 1, False), (100, 2, True), (99, 3, True),
+                                                 (1024, 2, "ahead")])
+def test_native_fetch_rccl_one_rank_self_loopback(hiplib, oracle, dim, rounds, bucketed):
+    """RcclTransport's grouped ncclSend / ncclRecv loop on the REAL transport.  RCCL cannot place two ranks on one device and a one-rank
+    communicator skips the loop (p == rank), so until round 4 that code -- the element type chosen from the row size (dim 100: int64 x 50
+    per row, dim 99: float x 99, dim 1024: int64 x 512), counts, displacements, the rounds on the communicator's own stream next to the
+    fills on the caller's -- had never executed.  coala_comm_set_self_loopback sends the own segment down the road of a peer's: ids by
+    ncclSend/ncclRecv to self, rows served into the staging buffer, shipped in `rounds` rounds by ncclSend/ncclRecv to self on the
+    comm stream, un-permuted (or, bucketed, received in place).  Rows, counters, tag table and cursors against the oracle."""
+    import torch
+    from COALA_GNN.COALA_GNN_Manager import NativeExchange
+    num_rows, cache_mb = 20000, 1
+    feat, tables, caches, orcs = _dist_fixture(hiplib, oracle, 1, dim, cache_mb, False, num_rows, seed=12, cls="Isolated_Cache")
+    ex = NativeExchange(None, 0, 0, 1, 0, rounds=rounds)        # a real RCCL communicator (ncclCommInitRank) of one rank
+    assert ex.rccl_ranks == 1
+    ex.set_self_loopback(True)
+    rng = np.random.default_rng(5)
+    stream = torch.cuda.Stream()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        for step, n in enumerate([1500, 0, 3000, 1, 2500, 2500]):
+            ids = rng.choice(num_rows // 2, size=n, replace=step == 5).astype(np.int64)
+            idx = torch.from_numpy(ids).cuda() if n else torch.zeros(0, dtype=torch.int64, device="cuda")
+            out = torch.full((max(n, 1), dim), -3.0, dtype=torch.float32, device="cuda")
+            stream.synchronize()
+            if bucketed:
+                cnt = torch.tensor([n], dtype=torch.int64, device="cuda")
+                ticket = None
+                if bucketed == "ahead":
+                    stream.synchronize()
+                    with torch.cuda.stream(side):
+                        ticket = ex.counts_begin(cnt.data_ptr())
+                ex.fetch_bucketed(caches[0], out.data_ptr() if n else 0, idx.data_ptr() if n else 0, n, cnt.data_ptr(), ticket=ticket)
+            else:
+                ex.fetch(caches[0], out.data_ptr() if n else 0, idx.data_ptr() if n else 0, n)
+            stream.synchronize()
+            want = oracle.dist_fetch(orcs, [ids], oracle.SCHED_HITS_FIRST)[0]
+            assert out[:n].cpu().numpy().tobytes() == feat[ids].tobytes() == want.tobytes(), f"step {step}: rows differ"
+            if n == 0:
+                assert float(out[0, 0]) == -3.0
+            assert caches[0].stats()[:2] == (orcs[0].hit_cnt, orcs[0].miss_cnt)
+            assert ex.last_send_counts == [n] and ex.last_recv_counts == [n]
+    keys, cnt_, _ = caches[0].dump()
+    assert np.array_equal(keys, orcs[0].keys()) and np.array_equal(cnt_, orcs[0].set_cnt())
+    assert orcs[0].hit_cnt > 0 and orcs[0].miss_cnt > 0
+    # ... and back: the same communicator without the loopback still delivers (own-shard bypass, no row exchange at one rank)
+    ex.set_self_loopback(False)
+    ids = rng.choice(num_rows // 2, size=800, replace=False).astype(np.int64)
+    idx = torch.from_numpy(ids).cuda()
+    out = torch.empty((800, dim), dtype=torch.float32, device="cuda")
+    ex.fetch(caches[0], out.data_ptr(), idx.data_ptr(), 800)
+    torch.cuda.synchronize()
+    assert out.cpu().numpy().tobytes() == feat[ids].tobytes()
+    ex.close()
+    caches[0].close()
+    tables[0].close()
+
+
+@pytest.mark.parametrize("G,dim,rounds", [(3, 100, 2), (2, 1024, 3)])
+def test_native_fetch_inproc_self_loopback_matches_oracle(hiplib, oracle, G, dim, rounds):
+    """The loopback orchestration (no own-shard bypass: own rows staged, exchanged with oneself, un-permuted) with G in-process ranks:
+    the delivered rows and every owner's table must be what the normal call produces -- i.e. what the oracle says."""
+    import ctypes as C
+    import threading
+    import torch
+    from COALA_GNN.COALA_GNN_Manager import NativeExchange
+    from COALA_GNN_Pybind import _capi
+    L = _capi.load()
+    num_rows, steps = 12000, 4
+    feat, tables, caches, orcs = _dist_fixture(hiplib, oracle, G, dim, 1, True, num_rows, seed=8, cls="Isolated_Cache")
+    group = C.c_void_p()
+    _capi.check(L.coala_comm_group_create(G, C.byref(group)))
+    exs = [NativeExchange(None, 0, r, G, 0, inproc_group=group, rounds=rounds) for r in range(G)]
+    for e in exs:
+        e.set_self_loopback(True)
+    rng = np.random.default_rng(91)
+    plan = [[rng.choice(num_rows // 2, size=int(rng.integers(1, 2500)), replace=False).astype(np.int64) for _ in range(G)] for _ in range(steps)]
+    got = [[None] * G for _ in range(steps)]
+    errors = []
+    bar = threading.Barrier(G, timeout=180)
+
+    def worker(r):
+        try:
+            torch.cuda.set_device(0)
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                for step in range(steps):
+                    ids = plan[step][r]
+                    idx = torch.from_numpy(ids).cuda()
+                    out = torch.full((len(ids), dim), -9.0, dtype=torch.float32, device="cuda")
+                    exs[r].fetch(caches[r], out.data_ptr(), idx.data_ptr(), len(ids))
+                    stream.synchronize()
+                    got[step][r] = out.cpu().numpy()
+                    bar.wait()
+        except BaseException as e:  # noqa: BLE001
+            errors.append((r, repr(e)))
+            bar.abort()
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(G)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    for step in range(steps):
+        want = oracle.dist_fetch(orcs, plan[step], oracle.SCHED_HITS_FIRST)
+        for r in range(G):
+            assert got[step][r].tobytes() == feat[plan[step][r]].tobytes() == want[r].tobytes(), f"rank {r} step {step}: rows differ"
+    for r in range(G):
+        keys, cnt, _ = caches[r].dump()
+        assert np.array_equal(keys, orcs[r].keys()) and np.array_equal(cnt, orcs[r].set_cnt())
+        assert caches[r].stats()[:2] == (orcs[r].hit_cnt, orcs[r].miss_cnt)
+    for e in exs:
+        e.close()
+    _capi.check(L.coala_comm_group_destroy(group))
+    for c in caches:
+        c.close()
+    for t in set(tables):
+        t.close()
+
+
 def test_native_fetch_over_rccl_two_gpus():
     """The fused native fetch over a REAL RCCL communicator between two distinct GPUs (bucketed and routed), against the table.
     Needs two visible GPUs: skipped on the one-GPU development / round-end boxes; it is what the driver's multi-GPU node exercises

@@ -161,6 +161,7 @@ def _bind_numa():
         return mod, {"applied": False, "why": repr(e)}
 
 
+ORIG_AFFINITY = os.sched_getaffinity(0)   # before the binding: what an "all cores" CPU baseline may use (run_cpu_baseline)
 _NUMA, NUMA_INFO = _bind_numa()
 
 import numpy as np  # noqa: E402
@@ -200,13 +201,13 @@ def parse_args():
     ap.add_argument("--epoch-steps", type=int, default=-1,
                     help="end-to-end leg (loader + GraphSAGE step): -1 = one FULL epoch per mode (measured, not extrapolated), "
                          "k > 0 = k steps extrapolated to an epoch, 0 = skip")
-    ap.add_argument("--epoch-prefetch-multi", dest="epoch_prefetch_multi", action="store_true", default=False,
-                    help="N>1: after the serial epoch leg has succeeded, also run it with the prefetching loader (producer thread).  "
-                         "OFF by default: the producer thread then issues the exchange's RCCL collectives while the consumer thread "
-                         "issues DDP's all-reduce on torch's communicator -- two communicators driven from two host threads with no "
+    ap.add_argument("--epoch-prefetch", "--epoch-prefetch-multi", dest="epoch_prefetch", action="store_true", default=False,
+                    help="after the default loader's epoch leg also run the leg with COALA_GNN_DataLoader(prefetch=2) (a producer thread).  "
+                         "OFF by default.  At N = 1 the two are level (8.9 s either way, profiles/r04_fetch_stream_packets.txt): the default "
+                         "loader already keeps fetch and sampler one and two steps ahead on their own streams from ONE host thread, so the "
+                         "line reports that one.  At N > 1 the producer thread would issue the exchange's RCCL collectives while the consumer "
+                         "thread issues DDP's all-reduce on torch's communicator -- two communicators driven from two host threads with no "
                          "cross-rank launch order, which RCCL documents as a deadlock risk and which has never run on two physical GPUs")
-    ap.add_argument("--no-epoch-prefetch-multi", dest="epoch_prefetch_multi", action="store_false",
-                    help="N>1: serial loader only (the default)")
     ap.add_argument("--epoch-timeout", type=float, default=150.0,
                     help="seconds after which an epoch leg is abandoned (never later than the run's --time-budget): the JSON line is printed "
                          "with an error field and every rank exits with code 3")
@@ -1076,11 +1077,12 @@ def run_epoch_leg(args, comm, graph, sampler, table, device, fanout, steps_per_e
         sys.setswitchinterval(float(os.environ["COALA_SWITCH_INTERVAL"]))
     if os.environ.get("COALA_EPOCH_MODES"):
         modes = [m for m in modes if m[0] in os.environ["COALA_EPOCH_MODES"].split(",")]
-    if world > 1 and not args.epoch_prefetch_multi:
+    if not args.epoch_prefetch:
         modes = modes[:1]
         out["prefetch"] = None
-        out["note"] = ("serial loader only at N>1 (one host thread issues the exchange's and DDP's collectives in one order on every rank); "
-                       "--epoch-prefetch-multi adds the producer-thread loader")
+        out["note"] = ("the default loader only: ONE host thread keeps the sampler two steps and the fetch one step ahead on their own streams (and, "
+                       "at N > 1, issues the exchange's and DDP's collectives in one order on every rank); --epoch-prefetch adds the "
+                       "producer-thread loader, which is level with it at N = 1")
     inject = os.environ.get("COALA_BENCH_INJECT_FAIL", "")  # test hook "rank:leg": that rank raises at the start of that leg
 
     def across_ranks(secs, nodes):
@@ -1206,10 +1208,41 @@ def _pmc_traffic(args, world):
         return None, None
 
 
+class _full_affinity(object):
+    """Every thread of this process (OpenMP workers and runtime helpers included) on ALL the CPUs the job was started with, for the
+    duration of the block: the NUMA binding done at import keeps a rank on its GPU's socket, and an "all cores" CPU baseline must not
+    inherit that handicap.  Restored afterwards, thread by thread."""
+
+    def __enter__(self):
+        self.saved = {}
+        full = ORIG_AFFINITY or os.sched_getaffinity(0)
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                self.saved[int(tid)] = os.sched_getaffinity(int(tid))
+                os.sched_setaffinity(int(tid), full)
+            except OSError:
+                pass
+        return len(full)
+
+    def __exit__(self, *exc):
+        for tid, mask in self.saved.items():
+            try:
+                os.sched_setaffinity(tid, mask)
+            except OSError:
+                pass
+        return False
+
+
+def _thread_counts(limit):
+    return [t for t in (1, 2, 4, 8, 16, 32, 64, 128, 192, 256, 384, 512) if t <= limit] or [1]
+
+
 def run_cpu_baseline(args, host_array, batches, fanout, graph=None, seeds_for=None):
-    """The CPU oracle (oracle/coala_oracle.c: a port, the reference itself cannot be built here) on one host core,
-    over a bounded sample of the same minibatches.  Also timed beside it, as BASELINE.md section 5 asks: the oracle's
-    sampler twin (one core) and torch.index_select over the host table with every core (DGL is not installed)."""
+    """The CPU oracle (oracle/coala_oracle.c: a port, the reference itself cannot be built here) on one host core, over a bounded
+    sample of the same minibatches.  Also timed beside it, as BASELINE.md section 5 asks: the CPU gather on many cores -- an OpenMP
+    row-memcpy gather (what `feat[input_nodes]` does on a host tensor) and torch.index_select, each with its thread count SWEPT and the
+    best one reported -- and the oracle's sampler twin, one core and swept (DGL is not installed).  The all-core legs run with the
+    process on every CPU it was started with, not on the NUMA node bench.py binds a rank to."""
     from oracle import oracle as O
     nb = min(args.cpu_baseline_batches, len(batches))
     if nb == 0:
@@ -1219,7 +1252,7 @@ def run_cpu_baseline(args, host_array, batches, fanout, graph=None, seeds_for=No
     t0 = time.perf_counter()
     rows = 0
     i = 0
-    while time.perf_counter() - t0 < 12.0:  # a bounded ~12 s sample: the same minibatches, cycled
+    while time.perf_counter() - t0 < 8.0:  # a bounded ~8 s sample: the same minibatches, cycled
         ids = idx_host[i % nb]
         orc.read_feature(ids, O.SCHED_HITS_FIRST)
         rows += len(ids)
@@ -1229,52 +1262,94 @@ def run_cpu_baseline(args, host_array, batches, fanout, graph=None, seeds_for=No
     res = {"value": round(rows * args.dim * 4 / dt / 1e9, 3), "unit": "GB/s", "cores": 1, "kind": "port",
            "sample": f"{rows} rows ({i} minibatches of the timed region, cycled) through the C oracle from a cold cache, {dt:.1f}s",
            "host_cpus": os.cpu_count()}
-    try:  # all-core gather: torch CPU index_select over the same pinned table
-        t = torch.from_numpy(host_array)
-        k = min(nb, 40)
-        t0 = time.perf_counter()
-        r2 = 0
-        for ids in idx_host[:k]:
-            torch.index_select(t, 0, torch.from_numpy(ids))
-            r2 += len(ids)
-        dt2 = time.perf_counter() - t0
-        res["index_select_all_cores"] = {"value": round(r2 * args.dim * 4 / dt2 / 1e9, 3), "unit": "GB/s", "threads": torch.get_num_threads(),
-                                         "ms_per_minibatch": round(dt2 / k * 1e3, 3)}
-    except Exception as e:  # noqa: BLE001
-        res["index_select_all_cores"] = {"error": str(e)[:100]}
-    if graph is not None and seeds_for is not None:  # CPU sampler (the oracle's twin of coala_sampler.hip), one core
-        ip, ix = graph.indptr.cpu().numpy(), graph.indices.cpu().numpy()
-        k = 20
-        t0 = time.perf_counter()
-        for s in range(k):
-            O.sample_blocks(ip, ix, seeds_for(s).cpu().numpy(), list(reversed(fanout)), args.seed, s)
-        res["sampler_twin_one_core_ms_per_minibatch"] = round((time.perf_counter() - t0) / k * 1e3, 3)
-        # ... and on many host cores (OpenMP: the draws over the destination nodes -- the counter-based RNG makes the result independent
-        # of the thread count -- and the first-appearance compaction as CAS inserts + a prefix sum).  A minibatch is ~1 ms of work on one
-        # core, so waking every core of a big host costs far more than it saves (128 threads: 665 ms per minibatch on the round-3 box):
-        # the thread count is swept and the best one is the baseline, with the whole sweep reported.
-        cores = len(os.sched_getaffinity(0))
-        sweep = {}
-        seeds_host = [seeds_for(s).cpu().numpy() for s in range(k)]
-        for th in [t for t in (2, 4, 8, 16, 32, 64, 128, 256) if t <= cores]:
-            O.sample_blocks(ip, ix, seeds_host[0], list(reversed(fanout)), args.seed, 0, threads=th)   # team start-up
-            t0 = time.perf_counter()
-            for s in range(k):
-                O.sample_blocks(ip, ix, seeds_host[s], list(reversed(fanout)), args.seed, s, threads=th)
-            sweep[th] = round((time.perf_counter() - t0) / k * 1e3, 3)
-            if sweep[th] > 20 * res["sampler_twin_one_core_ms_per_minibatch"]:
-                break                                                     # more threads only get slower from here
-        best = min(sweep, key=sweep.get) if sweep else 1
-        res["sampler_twin_all_cores"] = {"ms_per_minibatch": sweep.get(best), "cores": best, "cores_available": cores, "ms_by_threads": sweep,
-                                         "what": "OpenMP: draws over destination nodes per layer, compaction by CAS inserts + prefix sum; same blocks as "
-                                                 "one core; thread count swept, best reported"}
-    # extrapolated epoch of the CPU path = steps x (CPU sampler + best CPU gather), no training step
-    steps_per_epoch = int(0.6 * args.rows) // args.batch - 1
     ms_oracle = dt / max(i, 1) * 1e3
-    ms_gather = min(ms_oracle, res["index_select_all_cores"].get("ms_per_minibatch", ms_oracle))
-    res["epoch_time_s_extrapolated_sampler_plus_gather"] = round(
-        steps_per_epoch * (ms_gather + min(res.get("sampler_twin_one_core_ms_per_minibatch", 0.0),
-                                           res.get("sampler_twin_all_cores", {}).get("ms_per_minibatch", 1e9))) / 1e3, 1)
+    row_bytes = args.dim * 4
+    k = min(nb, 16)
+    with _full_affinity() as cpus_all:
+        res["all_core_legs_affinity"] = {"cpus": cpus_all, "numa_binding_of_the_rank": {kk: NUMA_INFO.get(kk) for kk in ("applied", "bound_node", "cpus")},
+                                         "note": "gather and sampler sweeps below run with every thread of the process on all CPUs of the job; the "
+                                                 "table sits on the GPU's NUMA node (hipHostMalloc)"}
+        # ---- OpenMP row-memcpy gather: the thread count swept, best reported; stops once more threads only get slower
+        try:
+            out = np.empty((max(len(x) for x in idx_host[:k]), args.dim), dtype=np.float32)
+            out[...] = 0.0                                  # touched before the clock runs
+            sweep = {}
+            for th in _thread_counts(cpus_all):
+                O.gather_rows_mt(host_array, idx_host[0], out, th)          # team start-up
+                t0 = time.perf_counter()
+                r2 = 0
+                for ids in idx_host[:k]:
+                    O.gather_rows_mt(host_array, ids, out, th)
+                    r2 += len(ids)
+                d2 = time.perf_counter() - t0
+                sweep[th] = round(r2 * row_bytes / d2 / 1e9, 3)
+                if th >= 8 and sweep[th] < 0.5 * max(sweep.values()):
+                    break
+            best = max(sweep, key=sweep.get)
+            res["gather_openmp_memcpy"] = {"value": sweep[best], "unit": "GB/s", "threads": best, "gbs_by_threads": sweep,
+                                           "ms_per_minibatch": round(np.mean([len(x) for x in idx_host[:k]]) * row_bytes / sweep[best] / 1e6, 3),
+                                           "what": "oracle/coala_oracle.c orc_gather_rows_mt: out[i] = table[idx[i]], one memcpy per row, rows dealt to "
+                                                   "OpenMP threads in blocks of 64; thread count swept, best reported"}
+            del out
+        except Exception as e:  # noqa: BLE001 -- a baseline leg never costs the line
+            res["gather_openmp_memcpy"] = {"error": repr(e)[:200]}
+        # ---- torch.index_select over the same pinned table, thread count swept the same way
+        try:
+            t = torch.from_numpy(host_array)
+            keep_threads = torch.get_num_threads()
+            sweep = {}
+            idx_t = [torch.from_numpy(x) for x in idx_host[:k]]
+            for th in _thread_counts(cpus_all):
+                torch.set_num_threads(th)
+                torch.index_select(t, 0, idx_t[0])
+                t0 = time.perf_counter()
+                r2 = 0
+                for ids in idx_t:
+                    torch.index_select(t, 0, ids)
+                    r2 += len(ids)
+                d2 = time.perf_counter() - t0
+                sweep[th] = round(r2 * row_bytes / d2 / 1e9, 3)
+                if th >= 8 and sweep[th] < 0.5 * max(sweep.values()):
+                    break
+            torch.set_num_threads(keep_threads)
+            best = max(sweep, key=sweep.get)
+            res["index_select_all_cores"] = {"value": sweep[best], "unit": "GB/s", "threads": best, "gbs_by_threads": sweep,
+                                             "ms_per_minibatch": round(np.mean([len(x) for x in idx_host[:k]]) * row_bytes / sweep[best] / 1e6, 3)}
+        except Exception as e:  # noqa: BLE001
+            res["index_select_all_cores"] = {"error": str(e)[:100]}
+        if graph is not None and seeds_for is not None:  # CPU sampler (the oracle's twin of coala_sampler.hip), one core
+            ip, ix = graph.indptr.cpu().numpy(), graph.indices.cpu().numpy()
+            ks = 20
+            seeds_host = [seeds_for(s).cpu().numpy() for s in range(ks)]
+            t0 = time.perf_counter()
+            for s in range(ks):
+                O.sample_blocks(ip, ix, seeds_host[s], list(reversed(fanout)), args.seed, s)
+            res["sampler_twin_one_core_ms_per_minibatch"] = round((time.perf_counter() - t0) / ks * 1e3, 3)
+            # ... and on many host cores (OpenMP: the draws over the destination nodes -- the counter-based RNG makes the result independent
+            # of the thread count -- and the first-appearance compaction as CAS inserts + a prefix sum).  A minibatch is ~1 ms of work on one
+            # core, so waking every core of a big host costs far more than it saves (128 threads: 665 ms per minibatch on the round-3 box):
+            # the thread count is swept and the best one is the baseline, with the whole sweep reported.
+            sweep = {}
+            for th in [t_ for t_ in _thread_counts(cpus_all) if t_ >= 2]:
+                O.sample_blocks(ip, ix, seeds_host[0], list(reversed(fanout)), args.seed, 0, threads=th)   # team start-up
+                t0 = time.perf_counter()
+                for s in range(ks):
+                    O.sample_blocks(ip, ix, seeds_host[s], list(reversed(fanout)), args.seed, s, threads=th)
+                sweep[th] = round((time.perf_counter() - t0) / ks * 1e3, 3)
+                if sweep[th] > 20 * res["sampler_twin_one_core_ms_per_minibatch"]:
+                    break                                                     # more threads only get slower from here
+            if sweep:
+                best = min(sweep, key=sweep.get)
+                res["sampler_twin_all_cores"] = {"ms_per_minibatch": sweep[best], "cores": best, "cores_available": cpus_all, "ms_by_threads": sweep,
+                                                 "what": "OpenMP: draws over destination nodes per layer, compaction by CAS inserts + prefix sum; same blocks as "
+                                                         "one core; thread count swept, best reported"}
+    # extrapolated epoch of the CPU path = steps x (best CPU sampler + best CPU gather), no training step
+    steps_per_epoch = int(0.6 * args.rows) // args.batch - 1
+    gathers = [ms_oracle] + [res[kk]["ms_per_minibatch"] for kk in ("gather_openmp_memcpy", "index_select_all_cores")
+                             if isinstance(res.get(kk), dict) and res[kk].get("ms_per_minibatch")]
+    samplers = [v for v in (res.get("sampler_twin_one_core_ms_per_minibatch"), (res.get("sampler_twin_all_cores") or {}).get("ms_per_minibatch")) if v]
+    res["best_cpu_gather_ms_per_minibatch"] = round(min(gathers), 3)
+    res["epoch_time_s_extrapolated_sampler_plus_gather"] = round(steps_per_epoch * (min(gathers) + (min(samplers) if samplers else 0.0)) / 1e3, 1)
     return res
 
 

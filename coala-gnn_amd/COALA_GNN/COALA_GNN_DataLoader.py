@@ -33,6 +33,26 @@ def _loader_streams(device):
     return _STREAMS[key]
 
 
+class _NativeEvent(object):
+    """The end event a fetch carries on its last kernel dispatch (COALA_GNN_Manager.last_done_event): same two uses as a torch event."""
+    __slots__ = ("handle",)
+
+    def __init__(self, handle):
+        self.handle = handle
+
+    def synchronize(self):
+        from COALA_GNN_Pybind import event_elapsed_ms
+        event_elapsed_ms(self.handle, self.handle, wait=True)
+
+
+def _wait_for(stream, ev):
+    if isinstance(ev, _NativeEvent):
+        from COALA_GNN_Pybind import stream_wait_event
+        stream_wait_event(ev.handle, int(stream.cuda_stream))
+    else:
+        stream.wait_event(ev)
+
+
 def _device_tensors(obj):
     if isinstance(obj, torch.Tensor):
         if obj.is_cuda:
@@ -135,7 +155,7 @@ class SSD_INFO(object):  # COALA_GNN_DataLoader.py:80-90
 class COALA_GNN_DataLoader(torch.utils.data.DataLoader):
     def __init__(self, SSD_info, node_distributor, graph, graph_sampler, batch_size, dim, fan_out, cache_size, device,
                  refresh_counter=10, cache_backend="nvshmem", sim_buf=None, shuffle=False, num_rows=None, profile=False,
-                 prefetch=0, cold_partitioned=False, sync_fetch=False, counts_ahead=None, fetch_depth=1):
+                 prefetch=0, cold_partitioned=False, sync_fetch=False, counts_ahead=None):
         # like the reference, torch's DataLoader.__init__ is never called: this is a plain iterator
         # prefetch = 0: the reference's strictly serial __next__ (:149-167).  prefetch = k > 0: a producer thread runs
         # distribute -> sample -> fetch for the next k steps on its own HIP stream while the consumer trains (SURVEY f-2).
@@ -147,10 +167,10 @@ class COALA_GNN_DataLoader(torch.utils.data.DataLoader):
         # synchronisation (coala_comm_counts_begin).  A fetch whose ticket has left the communicator's ring of pending count
         # exchanges falls back to the synchronous count (NativeExchange.fetch_bucketed) -- every rank makes the same calls in the same
         # order, so every rank falls back together.  Every rank of the cache group must use the same setting.
-        # fetch_depth (one-thread pipeline, prefetch = 0): how many fetches are kept enqueued on the fetch stream beyond the step being
-        # handed over (1: the fetch of step t+1 is enqueued when step t is handed over; the sampler runs one step further ahead).
         self.counts_ahead = counts_ahead
-        self.fetch_depth = max(1, int(fetch_depth))
+        # one-thread pipeline: fetches kept enqueued on the fetch stream beyond the step being handed over.  1 is enough: nothing on the
+        # host waits for the device, so the host runs far ahead of it anyway (2 measured level: profiles/r04_fetch_stream_packets.txt)
+        self.fetch_depth = 1
         self.prefetch = int(prefetch)
         self._producer = None
         self._queue = None
@@ -179,6 +199,11 @@ class COALA_GNN_DataLoader(torch.utils.data.DataLoader):
         self.COALA_GNN_Manager.sync_on_return = bool(sync_fetch)
         # the native sampler is stream-aware (it launches on torch's current stream); a foreign sampler keeps the caller's stream
         self._sample_on_side_stream = (not sync_fetch) and str(device).startswith("cuda") and getattr(graph_sampler, "stream_safe", False)
+        # The native sampler's sample_end() / sample() return only after the host has seen the completion event of the sample's LAST kernel
+        # (coala_sampler_wait): everything the fetch reads -- ids, blocks, owner counts -- is complete by then, and the fetch stream needs
+        # no device-side wait for the sampler's stream (one barrier packet less in front of every probe).  The count exchange issued ahead
+        # has its own event, waited for by the fetch itself.  A foreign sampler keeps the stream wait.
+        self._sampler_done_on_host = bool(getattr(graph_sampler, "completes_on_host", False))
         if self.counts_ahead is None:
             self.counts_ahead = bool(getattr(graph_sampler, "bucket_by_owner", 0)) and hasattr(self.COALA_GNN_Manager.exchange, "counts_begin")
         self.counts_ahead = bool(self.counts_ahead)
@@ -226,12 +251,12 @@ class COALA_GNN_DataLoader(torch.utils.data.DataLoader):
             batch[2][0].counts_ticket = ticket
         fs = self._side_stream
         with torch.cuda.stream(fs):
-            fs.wait_event(ev_s)
+            if not self._sampler_done_on_host:
+                fs.wait_event(ev_s)
             for t in _device_tensors(batch):
                 t.record_stream(fs)  # allocated on the sampler's stream, read by the fetch kernels
             item = self.COALA_GNN_Manager.fetch_feature(batch)
-            ev_f = torch.cuda.Event()
-            ev_f.record(fs)
+            ev_f = self._done_event(fs)
         self.counter += 1
         return item, ev_f
 
@@ -250,7 +275,7 @@ class COALA_GNN_DataLoader(torch.utils.data.DataLoader):
             item, ev = self._fetched.popleft()
             self._pump()
             cur = torch.cuda.current_stream()
-            cur.wait_event(ev)  # the consumer's stream sees the finished rows
+            _wait_for(cur, ev)  # the consumer's stream sees the finished rows
             for t in _device_tensors(item):
                 t.record_stream(cur)  # allocated on the side streams, used by the training step on this one
             return item
@@ -259,6 +284,16 @@ class COALA_GNN_DataLoader(torch.utils.data.DataLoader):
         batch = self.sampler.sample(self.g, seeds.to(self.device))
         self.counter += 1
         return self.COALA_GNN_Manager.fetch_feature(batch)
+
+    def _done_event(self, stream):
+        """The event that marks the rows of the fetch just enqueued complete: the one its last kernel carries, when the manager has
+        one (no packet of its own in the fetch stream's queue), else an event recorded behind it."""
+        nat = getattr(self.COALA_GNN_Manager, "last_done_event", None)
+        if nat:
+            return _NativeEvent(nat)
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        return ev
 
     def _pump(self):
         """Keep fetch_depth fetches enqueued and one sample launched beyond the last of them (same order of calls as ever: fetch t+1,
@@ -323,12 +358,12 @@ class COALA_GNN_DataLoader(torch.utils.data.DataLoader):
                     T["gpu_backlog"] += clock() - t0
                 t0 = clock()
                 with torch.cuda.stream(self._side_stream):
-                    self._side_stream.wait_event(ev_s)
+                    if not self._sampler_done_on_host:
+                        self._side_stream.wait_event(ev_s)
                     for t in _device_tensors(batch):
                         t.record_stream(self._side_stream)  # allocated on the sampler's stream, read by the fetch kernels
                     item = mgr.fetch_feature(batch)
-                    ev_f = torch.cuda.Event()
-                    ev_f.record(self._side_stream)
+                    ev_f = self._done_event(self._side_stream)
                 in_flight.append(ev_f)
                 T["fetch"] += clock() - t0
                 nxt = sample_next() if self.counter < self.total_count else None  # overlaps the fetch just enqueued
@@ -391,7 +426,7 @@ class COALA_GNN_DataLoader(torch.utils.data.DataLoader):
             raise got
         item, ev = got
         cur = torch.cuda.current_stream()
-        cur.wait_event(ev)  # the consumer's stream sees the finished rows
+        _wait_for(cur, ev)  # the consumer's stream sees the finished rows
         # Everything in the item was allocated on the producer's stream: tell the caching allocator that the consumer's
         # stream uses it too, or the memory can be handed to the producer's next step while consumer kernels still read it
         # (seen as garbage neighbour indices -> device-side index assert).

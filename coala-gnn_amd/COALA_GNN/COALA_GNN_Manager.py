@@ -407,6 +407,12 @@ class COALA_GNN_Manager(object):
         # wall time.  False: fully stream-ordered, no host wait; the timer is then fed by a pair of HIP events per call.
         self.sync_on_return = True
         self._agg_events = []
+        # Stream-ordered mode, isolated backend: the begin / end events of a fetch ride on its two kernel dispatches
+        # (coala_cache_fetch_events) instead of being recorded as packets of their own -- on a stream that carries nothing but
+        # fetches, every extra packet between the cold fill of one minibatch and the probe of the next is 6-12 us of idle link.
+        # last_done_event: the native end event of the most recent fetch (None: the caller records one itself).
+        self.last_done_event = None
+        self._native_events = False
         if not self.is_simulation:
             raise RuntimeError("sim_buf is None: the NVMe/BaM tier is out of scope here; pass the pinned feature table "
                                "(the reference's --feat_cpu mode, used by every published script)")
@@ -460,6 +466,9 @@ class COALA_GNN_Manager(object):
                                                   cold_partitioned=cold_partitioned and self.cache_backend == "nccl")
             if cold_partitioned and self.cache_backend == "isolated":
                 raise ValueError("an isolated cache reads every row: it needs the whole cold table, not an owner's shard")
+            if self.cache_backend == "isolated" and not profile and hasattr(self.COALA_GNN_Cache, "fetch_events"):
+                self.COALA_GNN_Cache.fetch_events(True)
+                self._native_events = True
             if self.cache_backend == "nccl":
                 self.exchange = make_exchange()
         else:
@@ -474,7 +483,9 @@ class COALA_GNN_Manager(object):
         index_ptr = index.data_ptr()
         fetch_start = time.time()
         ev_pair = None
-        if not self.sync_on_return:
+        self.last_done_event = None
+        native_ev = (not self.sync_on_return) and self._native_events and index_size > 0
+        if not self.sync_on_return and not native_ev:
             ev_pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev_pair[0].record()
 
@@ -513,6 +524,14 @@ class COALA_GNN_Manager(object):
         if self.sync_on_return:
             torch.cuda.current_stream().synchronize()
             self.aggregation_timer += (time.time() - fetch_start)
+        elif native_ev:
+            a, b = self.COALA_GNN_Cache.last_fetch_events()
+            if b:
+                self.last_done_event = b
+                self._agg_events.append((a, b))
+            if len(self._agg_events) >= 64 and (len(self._agg_events) % 64 == 0 or len(self._agg_events) >= 1024):
+                # (the handle keeps 2048 pairs: a host that runs far ahead of the device waits here, at 1024 unread ones)
+                self._fold_events(wait=len(self._agg_events) >= 1024)
         else:
             ev_pair[1].record()
             self._agg_events.append(ev_pair)
@@ -574,8 +593,16 @@ class COALA_GNN_Manager(object):
 
     def _fold_events(self, wait):
         """Move finished (start, end) event pairs into the aggregation timer; with wait=True, all of them."""
+        from COALA_GNN_Pybind import event_elapsed_ms
         keep = []
         for a, b in self._agg_events:
+            if isinstance(b, int):           # native pair: begin on the first kernel of the fetch, end on the last
+                ms = None if keep else event_elapsed_ms(a, b, wait=wait)   # (events of one stream complete in order)
+                if ms is None:
+                    keep.append((a, b))
+                else:
+                    self.aggregation_timer += ms * 1e-3
+                continue
             if wait:
                 b.synchronize()
             if b.query():

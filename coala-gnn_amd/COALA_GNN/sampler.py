@@ -137,6 +137,7 @@ class Block(object):
 
 class NeighborSampler(object):
     stream_safe = True  # every kernel and allocation of sample() goes to torch's current stream
+    completes_on_host = True  # sample() / sample_end() return after the host has seen the event behind the sample's last kernel (coala_sampler_wait)
 
     def __init__(self, fanouts, seed=0, bucket_by_owner=0):
         self.fanouts = [int(f) for f in fanouts]

@@ -62,6 +62,21 @@ def current_stream():
     return int(_stream_provider())
 
 
+def stream_wait_event(event, stream=None):
+    """The stream (default: the current one) waits for a native event handle (hipStreamWaitEvent; no host wait)."""
+    _capi.check(_lib.coala_stream_wait_event(current_stream() if stream is None else stream, event))
+
+
+def event_elapsed_ms(begin, end, wait=True):
+    """Milliseconds between two native event handles; None while `end` has not completed (wait=False)."""
+    ms = C.c_float(0.0)
+    rc = _lib.coala_event_elapsed_ms(begin, end, 1 if wait else 0, C.byref(ms))
+    if rc == 1:
+        return None
+    _capi.check(rc)
+    return float(ms.value)
+
+
 def _local_rank_from_env():
     for k in ("LOCAL_RANK", "SLURM_LOCALID"):
         if k in os.environ:
@@ -253,6 +268,17 @@ class _CacheBase:
         p = CacheProfile()
         check(_lib.coala_cache_profile(self._h, C.byref(p), int(reset)))
         return p
+
+    def fetch_events(self, enable=True):
+        """coala_cache_fetch_events: begin / end events attached to the kernels of every read_feature (no packets of their own)."""
+        _capi.check(_lib.coala_cache_fetch_events(self._h, 1 if enable else 0))
+
+    def last_fetch_events(self):
+        """(begin, end) native event handles of the most recent read_feature, or (None, None): wait with stream_wait_event(), time with
+        event_elapsed_ms()."""
+        a, b = C.c_void_p(), C.c_void_p()
+        _capi.check(_lib.coala_cache_last_fetch_events(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def dump(self):
         """(keys[sets,32] u64, set_cnt[sets] u32, color_meta[sets,32] u32) as numpy arrays (test/debug)."""

@@ -67,6 +67,10 @@ SYMBOLS = {
     "coala_cache_scatter": (_I, [_VP, _VP, _VP, _VP, _I64, _VP]),
     "coala_cache_scatter_ranges": (_I, [_VP, _VP, _VP, _VP, C.POINTER(_I64), C.POINTER(_I64), _I, _VP]),
     "coala_cache_row_dim": (_I64, [_VP]),
+    "coala_cache_fetch_events": (_I, [_VP, _I]),
+    "coala_cache_last_fetch_events": (_I, [_VP, C.POINTER(_VP), C.POINTER(_VP)]),
+    "coala_stream_wait_event": (_I, [_VP, _VP]),
+    "coala_event_elapsed_ms": (_I, [_VP, _VP, _I, C.POINTER(C.c_float)]),
     "coala_comm_unique_id": (_I, [_VP, _SZ]),
     "coala_comm_create": (_I, [_VP, _I, _I, _I, C.POINTER(_VP)]),
     "coala_comm_destroy": (_I, [_VP]),

@@ -842,6 +842,13 @@ struct coala_cache {
     uint64_t rows_total = 0;              // rows submitted since the last stats reset (hits = rows - misses - rejected)
     uint64_t cum_hit = 0, cum_miss = 0;   // totals folded in whenever coala_cache_stats resets the device counters
     uint64_t prof_hit0 = 0, prof_miss0 = 0; // totals at the last profile reset
+    // coala_cache_fetch_events: a begin event on the first kernel and an end event on the last kernel of every read_feature call, attached
+    // to the dispatches themselves (no packets of their own); a ring, so that a caller far ahead of the device can still read old pairs
+    bool fetch_events = false;
+    static constexpr int kFetchRing = 2048;
+    std::vector<hipEvent_t> fev;          // [2 * kFetchRing], created on first use
+    uint64_t fev_calls = 0;
+    hipEvent_t last_begin = nullptr, last_end = nullptr;
 };
 
 namespace {
@@ -908,7 +915,9 @@ void drain_events(coala_cache* h) {
 // itself), i.e. what rocprofv3 reports for the launch -- a separate hipEventRecord bracket adds the 2-5 us between two packets.
 struct ProfScope {
     coala_cache* h; hipStream_t s; int kind; uint64_t rows; hipEvent_t a = nullptr, b = nullptr; bool on;
-    ProfScope(coala_cache* h_, hipStream_t s_, int kind_, uint64_t rows_) : h(h_), s(s_), kind(kind_), rows(rows_) {
+    hipEvent_t xa = nullptr, xb = nullptr; // without profiling: the caller's own begin / end event for this launch (coala_cache_fetch_events)
+    ProfScope(coala_cache* h_, hipStream_t s_, int kind_, uint64_t rows_, hipEvent_t xa_ = nullptr, hipEvent_t xb_ = nullptr)
+        : h(h_), s(s_), kind(kind_), rows(rows_), xa(xa_), xb(xb_) {
         on = (h->cfg.flags & COALA_FLAG_PROFILE) != 0;
         if (on) {
             if (h->ev_live.size() >= 8192) drain_events(h);
@@ -920,6 +929,7 @@ struct ProfScope {
     template <typename K, typename... Args>
     void launch(K kernel, dim3 grid, dim3 block, Args... args) {
         if (on) hipExtLaunchKernelGGL(kernel, grid, block, 0, s, a, b, 0, args...);
+        else if (xa || xb) hipExtLaunchKernelGGL(kernel, grid, block, 0, s, xa, xb, 0, args...);
         else hipLaunchKernelGGL(kernel, grid, block, 0, s, args...);
     }
     ~ProfScope() {
@@ -1113,6 +1123,8 @@ int coala_cache_destroy(coala_cache_t* h) {
     (void)hipDeviceSynchronize();
     drain_events(h);
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
+    for (auto e : h->fev)
+        if (e) (void)hipEventDestroy(e);
     CacheDev& d = h->d;
     void* ptrs[] = {d.keys, d.set_cnt, d.color_meta, d.set_head, d.stats, d.lines, d.color_counters,
                     h->node_color_dev, d.miss_link,
@@ -1128,6 +1140,41 @@ int coala_cache_destroy(coala_cache_t* h) {
 }
 
 int64_t coala_cache_row_dim(const coala_cache_t* h) { return h ? (int64_t)h->d.dim : 0; }
+
+int coala_cache_fetch_events(coala_cache_t* h, int enable) {
+    if (!h) return fail(COALA_EINVAL, "null handle");
+    h->fetch_events = enable != 0;
+    if (!h->fetch_events) h->last_begin = h->last_end = nullptr;
+    return COALA_OK;
+}
+
+int coala_cache_last_fetch_events(const coala_cache_t* h, void** begin_ev, void** end_ev) {
+    if (!h) return fail(COALA_EINVAL, "null handle");
+    if (begin_ev) *begin_ev = (void*)h->last_begin;
+    if (end_ev) *end_ev = (void*)h->last_end;
+    return COALA_OK;
+}
+
+int coala_stream_wait_event(void* stream, void* event) {
+    if (!event) return fail(COALA_EINVAL, "null event");
+    HIPCHK(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));
+    return COALA_OK;
+}
+
+int coala_event_elapsed_ms(void* begin_ev, void* end_ev, int wait, float* ms_out) {
+    if (!begin_ev || !end_ev || !ms_out) return fail(COALA_EINVAL, "null argument");
+    if (wait) HIPCHK(hipEventSynchronize((hipEvent_t)end_ev));
+    else {
+        const hipError_t q = hipEventQuery((hipEvent_t)end_ev);
+        if (q == hipErrorNotReady) {
+            (void)hipGetLastError();
+            return 1; // not finished yet: no error, no message
+        }
+        if (q != hipSuccess) return fail(COALA_EHIP, "hipEventQuery failed: %s", hipGetErrorString(q));
+    }
+    HIPCHK(hipEventElapsedTime(ms_out, (hipEvent_t)begin_ev, (hipEvent_t)end_ev));
+    return COALA_OK;
+}
 
 int coala_cache_geometry(const coala_cache_t* h, coala_cache_geometry_t* out) {
     if (!h || !out) return fail(COALA_EINVAL, "null argument");
@@ -1147,6 +1194,7 @@ static int read_feature_impl(coala_cache_t* h, float* out, const int64_t* idx, i
                              int phases, const int64_t* begins, const int64_t* ends, int n_ranges,
                              const coala_row_redirect_t* redirect) {
     if (!h) return fail(COALA_EINVAL, "null handle");
+    h->last_begin = h->last_end = nullptr; // (set again below when this call launches a whole read with its events attached)
     if (n < 0 || n > 0x7FFFFFFFll) return fail(COALA_EINVAL, "n=%lld out of range", (long long)n);
     if (phases & kPhaseProbe) {
         // a batch that was probed and not completely filled still owns the verdict words and the per-set miss chains: a second
@@ -1216,13 +1264,23 @@ static int read_feature_impl(coala_cache_t* h, float* out, const int64_t* idx, i
     const bool vec4 = (h->d.dim % 4 == 0) && aligned16(out) && aligned16(h->d.cold) && (!redir || aligned16(rd.out));
     CacheDev d = h->d;
     if (force_dist) d.distributed = 1u;
+    // a whole read (K1 + one K2 launch): its begin / end events ride on the two dispatches (see coala_cache_fetch_events)
+    hipEvent_t fe_begin = nullptr, fe_end = nullptr;
+    if (h->fetch_events && phases == kPhaseBoth && !(h->cfg.flags & COALA_FLAG_PROFILE)) {
+        if (h->fev.empty()) h->fev.assign(2 * (size_t)coala_cache::kFetchRing, nullptr);
+        const size_t slot = (size_t)(h->fev_calls % coala_cache::kFetchRing);
+        for (size_t k = 2 * slot; k < 2 * slot + 2; ++k)
+            if (!h->fev[k]) HIPCHK(hipEventCreate(&h->fev[k]));
+        fe_begin = h->fev[2 * slot];
+        fe_end = h->fev[2 * slot + 1];
+    }
     rc = dispatch_geo(d.cache_dim, vec4, [&](auto geo) -> int {
         constexpr int CD = geo_cd(geo);
         constexpr int VEC = geo_vec(geo);
         using G = Geo<CD, VEC>;
         // K1: 2-wave blocks, every wave resident; grid-stride over the chunks
         if (phases & kPhaseProbe) {
-            ProfScope ps(h, s, 0, (uint64_t)n);
+            ProfScope ps(h, s, 0, (uint64_t)n, fe_begin, nullptr);
             const bool full = (VEC == 4) && ((int)d.dim == CD);
             auto launch_k1 = [&](auto tag_c, auto np_c) {
                 using TAG = decltype(tag_c);
@@ -1268,7 +1326,7 @@ static int read_feature_impl(coala_cache_t* h, float* out, const int64_t* idx, i
             // verdict tile: 64 rows behind the narrow host-tier grid, one chunk behind the wide HBM-tier grid (see the kernel)
             const int tile_rows = h->k2_tile_rows > 0 ? h->k2_tile_rows : G::R;
             return for_each_range_set(begins, ends, n_ranges, [&](const RangeSet& rs) -> int {
-                ProfScope ps(h, s, 2, 0);
+                ProfScope ps(h, s, 2, 0, nullptr, fe_end);
                 const int64_t tiles = ((int64_t)rs.total + tile_rows - 1) / tile_rows;
                 const dim3 grid(grid_for(tiles, 4, h->k2_grid_cap));
                 if (redir) ps.launch(miss_fill_kernel<CD, VEC, true>, grid, dim3(256), d, idx, out, tile_rows, h->k2_sparse_max, gen, rs, rd);
@@ -1279,6 +1337,11 @@ static int read_feature_impl(coala_cache_t* h, float* out, const int64_t* idx, i
         return COALA_OK;
     });
     if (rc) return rc;
+    if (fe_begin) {
+        h->last_begin = fe_begin;
+        h->last_end = fe_end;
+        h->fev_calls++;
+    }
     if (phases & kPhaseProbe) h->rows_total += (uint64_t)n;
     if (phases == kPhaseFill) {
         h->open_filled_rows += fill_rows;

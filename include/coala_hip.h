@@ -220,6 +220,23 @@ int coala_cache_fetch_distributed_bucketed(coala_cache_t* h, coala_comm_t* c, fl
 int coala_comm_counts_begin(coala_comm_t* c, const int64_t* counts_dev, void* stream, int64_t* ticket_out);
 int coala_cache_fetch_distributed_bucketed_ahead(coala_cache_t* h, coala_comm_t* c, float* out, const int64_t* idx, int64_t n,
                                                  int64_t ticket, void* stream);
+/* ------------------------------------------------------------------------------------------------------------
+ * Completion and timing of a read WITHOUT packets of their own.  A hipEventRecord is one more barrier packet in the stream's
+ * queue; on a stream that carries nothing but the fetches of consecutive minibatches (the loader's fetch stream) every such
+ * packet is 6-12 us of idle link between the cold fill of one minibatch and the probe of the next.
+ * With coala_cache_fetch_events(h, 1) every coala_cache_read_feature attaches a begin event to its first kernel launch and an
+ * end event to its last one (hipExtLaunchKernelGGL: the events ride on the two dispatch packets).  coala_cache_last_fetch_events
+ * hands out the pair of the most recent call -- owned by the handle, valid for the next 2048 calls, NULL when that call launched
+ * nothing (n = 0), when the handle profiles (COALA_FLAG_PROFILE uses the dispatches' event slots itself) or for the split-phase
+ * serve calls: the caller then records an event of its own.  A consumer on another stream waits with coala_stream_wait_event
+ * (hipStreamWaitEvent); coala_event_elapsed_ms gives begin -> end in milliseconds (wait = 0: returns 1, no error, while the end
+ * event has not completed).  The reference synchronises the device after every call instead (ssd_gnn_cache.cuh:266).
+ * ------------------------------------------------------------------------------------------------------------ */
+int coala_cache_fetch_events(coala_cache_t* h, int enable);
+int coala_cache_last_fetch_events(const coala_cache_t* h, void** begin_ev, void** end_ev);
+int coala_stream_wait_event(void* stream, void* event);
+int coala_event_elapsed_ms(void* begin_ev, void* end_ev, int wait, float* ms_out);
+
 /* Timing of the row exchange (all rounds of a fetch, HIP events on the communicator's stream; includes any wait for the fill of
  * a later round): enable = 1 / 0 switches it, -1 leaves it; out (nullable) receives the totals since the last reset. */
 typedef struct coala_comm_profile {

@@ -384,6 +384,29 @@ int orc_sample_layer_mt(const int64_t* indptr, const int64_t* indices, int64_t n
     return used;
 }
 
+/* CPU feature gather on `threads` host threads (OpenMP): out[i, :] = table[idx[i], :], one memcpy per row -- what the reference's CPU path
+ * does with `feat[input_nodes]` on a row-major fp32 host tensor before the copy to the GPU (BASELINE.json configs[0]; DGL / torch index_select).
+ * For bench.py's cpu_baseline leg only (the gather on the box's host cores).  Rows are dealt out in blocks of 64 so
+ * that a thread streams whole rows and neighbouring threads do not share output cache lines.  Returns the number of threads OpenMP gave. */
+int orc_gather_rows_mt(const float* table, int64_t dim, const int64_t* idx, int64_t n, float* out, int threads) {
+    int used = 1;
+    const size_t row = (size_t)dim * sizeof(float);
+#ifdef _OPENMP
+    if (threads < 1) threads = 1;
+#pragma omp parallel num_threads(threads)
+    {
+#pragma omp single
+        used = omp_get_num_threads();
+#pragma omp for schedule(static, 64)
+        for (int64_t i = 0; i < n; ++i) memcpy(out + (size_t)i * dim, table + (size_t)idx[i] * dim, row);
+    }
+#else
+    (void)threads;
+    for (int64_t i = 0; i < n; ++i) memcpy(out + (size_t)i * dim, table + (size_t)idx[i] * dim, row);
+#endif
+    return used;
+}
+
 typedef struct { int64_t key; int32_t val; } orc_slot;
 
 int64_t orc_compact_block(const int64_t* dst, int64_t n_dst, const int64_t* nbr, int fanout, int64_t* src_out, int32_t* local) {

@@ -73,6 +73,8 @@ def lib():
         L.orc_fill_features.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]
         L.orc_sample_layer.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_uint64,
                                        C.c_uint64, C.c_int, C.c_void_p]
+        L.orc_gather_rows_mt.restype = C.c_int
+        L.orc_gather_rows_mt.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]
         L.orc_sample_layer_mt.restype = C.c_int
         L.orc_sample_layer_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_uint64,
                                           C.c_uint64, C.c_int, C.c_void_p, C.c_int]
@@ -253,6 +255,14 @@ def sample_blocks(indptr, indices, seeds, fanouts_reversed, seed, step, threads=
         out.append((src, local.reshape(len(dst), f), nbr.reshape(len(dst), f)))
         dst = src
     return out
+
+
+def gather_rows_mt(table, idx, out, threads):
+    """out[i, :] = table[idx[i], :] on `threads` OpenMP threads (row memcpy); -> threads OpenMP actually used."""
+    assert table.dtype == np.float32 and table.flags.c_contiguous and out.dtype == np.float32 and out.flags.c_contiguous
+    idx = np.ascontiguousarray(idx, dtype=np.int64)
+    assert out.shape[0] >= len(idx) and out.shape[1] == table.shape[1]
+    return int(lib().orc_gather_rows_mt(_ptr(table), table.shape[1], _ptr(idx), len(idx), _ptr(out), int(threads)))
 
 
 def npy_parse(buf, want_dim):

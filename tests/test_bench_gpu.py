@@ -42,7 +42,7 @@ def test_bench_single_gpu_contract():
     assert {"value", "unit", "cores", "kind", "sample"} <= set(c) and c["kind"] == "port" and c["value"] > 0
     assert r["traffic_source"] is None          # not the profiled default command line -> no PMC constant is quoted
     e = d["epoch"]
-    assert e["serial"]["steps"] == 12 and e["prefetch"]["steps"] == 12 and e["serial"]["ms_per_step"] > 0
+    assert e["serial"]["steps"] == 12 and e["prefetch"] is None and e["serial"]["ms_per_step"] > 0   # one loader in the line (--epoch-prefetch adds the other)
     x = d["config_fanout_10_10"]                # the 10,10 batch shape has an N = 1 origin too
     assert x["value"] > 0 and x["steps"] == 60 and x["rows_per_step_per_gpu"] > d["config"]["rows_per_step_per_gpu"]
 
@@ -134,7 +134,7 @@ def test_bench_one_rank_rccl_rehearsal():
     its OWN one-rank RCCL communicator (ranks as ncclCommCount reports them), sampler-bucketed ids, count exchanges issued ahead, and
     the epoch leg under DistributedDataParallel (torch's RCCL communicator next to the exchange's) -- what the multi-GPU run does,
     minus bytes on a link.  Runs on the driver's one-GPU box every round."""
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *SMALL, "--backend", "nccl", "--no-fanout-leg"], capture_output=True,
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *SMALL, "--backend", "nccl", "--no-fanout-leg", "--epoch-prefetch"], capture_output=True,
                          text=True, timeout=900)
     d = _line(out)
     c = d["config"]

@@ -338,3 +338,58 @@ def test_calls_that_change_streams_keep_their_order(hiplib, torch_cuda):
         assert torch.equal(outs[0], want) and torch.equal(outs[1], want)
     cache.close()
     table.close()
+
+
+def test_fetch_events_ride_on_the_dispatches(hiplib, oracle, torch_cuda):
+    """coala_cache_fetch_events: the begin / end events of a read are attached to its first / last kernel launch (no packets of their
+    own).  A consumer on ANOTHER stream that waits for the end event (coala_stream_wait_event) must see every row of a cold read --
+    20,000 x 4 KiB over PCIe, ~1.5 ms after the call returned -- and begin -> end must be the duration of that read.  n = 0 and a
+    profiling handle hand out no events (the caller then records its own)."""
+    torch = torch_cuda
+    P = hiplib
+    dim, num_rows, n = 1024, 60000, 20000
+    feat = oracle.make_features(num_rows, dim, seed=21)
+    table = PinnedTable(P, feat)
+    cache, _ = _make_cache(P, table, 256, sync=False)
+    cache.fetch_events(True)
+    rng = np.random.default_rng(4)
+    producer, consumer = torch.cuda.Stream(), torch.cuda.Stream()
+    for step in range(3):           # step 0: all misses; later steps: hits and misses
+        ids = rng.choice(num_rows, size=n, replace=False).astype(np.int64)
+        idx = torch.from_numpy(ids).cuda()
+        out = torch.full((n, dim), -1.0, dtype=torch.float32, device="cuda")
+        copy = torch.full((n, dim), -2.0, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        with torch.cuda.stream(producer):
+            bracket = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            bracket[0].record()
+            cache.read_feature(out.data_ptr(), idx.data_ptr(), n)
+            bracket[1].record()
+        begin, end = cache.last_fetch_events()
+        assert begin and end
+        with torch.cuda.stream(consumer):
+            P.stream_wait_event(end)            # the consumer's (current) stream waits; the host does not
+            copy.copy_(out)
+        consumer.synchronize()
+        assert copy.cpu().numpy().tobytes() == feat[ids].tobytes(), f"step {step}: the consumer ran ahead of the read"
+        ms = P.event_elapsed_ms(begin, end, wait=True)
+        producer.synchronize()
+        outer = bracket[0].elapsed_time(bracket[1])
+        assert 0.0 < ms <= outer + 0.05 and ms > 0.5 * outer, (ms, outer)
+    cache.read_feature(0, 0, 0)
+    assert cache.last_fetch_events() == (None, None)
+    cache.fetch_events(False)
+    idx = torch.arange(100, device="cuda")
+    out = torch.empty((100, dim), dtype=torch.float32, device="cuda")
+    cache.read_feature(out.data_ptr(), idx.data_ptr(), 100)
+    assert cache.last_fetch_events() == (None, None)
+    torch.cuda.synchronize()
+    cache.close()
+    prof, _ = _make_cache(P, table, 16, profile=True, sync=False)
+    prof.fetch_events(True)
+    prof.read_feature(out.data_ptr(), idx.data_ptr(), 100)
+    assert prof.last_fetch_events() == (None, None)      # the profiling handle uses the dispatches' event slots itself
+    torch.cuda.synchronize()
+    assert out.cpu().numpy().tobytes() == feat[:100].tobytes()
+    prof.close()
+    table.close()

@@ -5,7 +5,7 @@ were doing during every large gap: the host-side calls of the loader (scheduler,
 wall-clock intervals, every garbage collection of the interpreter, every growth of the caching allocator's reserved memory, and the
 completion time of the sample the late fetch waited for, all mapped onto one time axis.  Development tool.
 
-  STEPS=2400 PREFETCH=0|2 REFRESH=10 TRAIN=1 WHY=1 GCFREEZE=1 DEPTH=<fetches ahead> python tools/fetch_gap_probe.py
+  STEPS=2400 PREFETCH=0|2 REFRESH=10 TRAIN=1 WHY=1 GCFREEZE=1 NATIVE_EVENTS=1|0 SAMPLER_WAIT=0|1 python tools/fetch_gap_probe.py
 """
 import gc
 import os
@@ -38,11 +38,13 @@ sampler = NeighborSampler(fan, seed=0)
 g = sampler.make_graph(indptr, indices, ndata={"labels": (torch.arange(rows, device="cuda") * 7) % 19})
 nd = Node_Distributor(comm, ids, batch, *files, parsing_method="baseline")
 kw = {}
-if os.environ.get("DEPTH"):
-    kw["fetch_depth"] = int(os.environ["DEPTH"])
 loader = COALA_GNN_DataLoader(SSD_INFO(1, 4096, 1024, 0), nd, g, sampler, batch, dim, fan, 4096, "cuda:0", cache_backend="isolated", sim_buf=table,
                               num_rows=rows, prefetch=int(os.environ.get("PREFETCH", "2")), refresh_counter=int(os.environ.get("REFRESH", "10")), **kw)
 mgr = loader.COALA_GNN_Manager
+if os.environ.get("NATIVE_EVENTS", "1") == "0":   # A/B: the round-3 form (timing pair + completion event recorded as packets of their own)
+    mgr.COALA_GNN_Cache.fetch_events(False); mgr._native_events = False
+if os.environ.get("SAMPLER_WAIT", "0") == "1":    # A/B: the fetch stream waits for the sampler's stream on the device, as until round 3
+    loader._sampler_done_on_host = False
 pairs = []
 def keep(wait):  # keep every (start, end) event pair instead of folding them away
     pairs.extend(mgr._agg_events); mgr._agg_events = []
@@ -100,7 +102,10 @@ t0 = clock(); n = 0
 last_res = torch.cuda.memory_reserved()
 step_host = []   # host time at which the consumer received step n
 step_ev = []     # event on the training stream behind the optimizer step of step n
+t_warm = None
 for inp, sd, blocks, feat in loader:
+    if n == 1200:   # the steady state by the host clock too (the only figure when the fetches carry no event pairs: TIMING_STRIDE)
+        torch.cuda.synchronize(); t_warm = clock()
     if WHY:
         step_host.append(clock())
     if train:
@@ -114,10 +119,16 @@ for inp, sd, blocks, feat in loader:
     n += 1
 torch.cuda.synchronize(); dt = clock() - t0
 keep(True)
+print(f"train={train} prefetch={loader.prefetch} native_events={mgr._native_events} sampler_wait={not loader._sampler_done_on_host}: "
+      f"steady state by the host clock (steps 1200..{n}): {(t0 + dt - t_warm) / (n - 1200) * 1e3:.4f} ms/step" if t_warm else "")
 warm = min(1200, max(0, len(pairs) - 400))  # steady state only
-dur = [a.elapsed_time(b) for a, b in pairs[warm:]]
-gap = [pairs[i][1].elapsed_time(pairs[i + 1][0]) for i in range(warm, len(pairs) - 1)]
-print(f"train={train} prefetch={loader.prefetch} refresh_counter={loader.refresh_counter} depth={getattr(loader, 'fetch_depth', 1)}: {n} steps, {dt / n * 1e3:.3f} ms/step overall (cold start included)")
+from COALA_GNN_Pybind import event_elapsed_ms
+def el(a, b):   # ms between two events, torch's or the native handles a fetch carries on its dispatches (valid for 2048 fetches: the steady state fits)
+    h = lambda e: e if isinstance(e, int) else int(e.cuda_event)
+    return event_elapsed_ms(h(a), h(b), wait=True)
+dur = [el(a, b) for a, b in pairs[warm:]]
+gap = [el(pairs[i][1], pairs[i + 1][0]) for i in range(warm, len(pairs) - 1)]
+print(f"train={train} prefetch={loader.prefetch} refresh_counter={loader.refresh_counter} : {n} steps, {dt / n * 1e3:.3f} ms/step overall (cold start included)")
 print(f"  steady state ({len(dur)} fetches): fetch duration mean {st.mean(dur):.4f} ms, median {st.median(dur):.4f} ms; idle gap between fetches mean {st.mean(gap):.4f} ms, "
       f"median {st.median(gap):.4f} ms; sum = {st.mean(dur) + st.mean(gap):.4f} ms/step")
 for thr in (0.05, 0.2, 0.5, 1.0):
@@ -129,7 +140,7 @@ print("  positions (step mod 10) of the first gaps > 0.2 ms:", [(warm + i + 1) %
 if WHY:
     # one axis: host seconds.  A GPU event e happened at t_base + base.elapsed_time(e) / 1e3 (the two clocks drift by microseconds over seconds)
     def at(e):
-        return t_base + base.elapsed_time(e) * 1e-3
+        return t_base + el(base, e) * 1e-3
     fetch_calls = [h for h in host if h[0] == "fetch_feature"]
     print(f"  WHY: {len(gcs)} garbage collections in the loop (by generation: { {k: sum(1 for g_ in gcs if g_[0] == k) for k in (0, 1, 2)} }, "
           f"total {sum(b - a for _, a, b in gcs) * 1e3:.1f} ms), allocator reserved memory changed {len(reserved)} times in the loop "

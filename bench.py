@@ -217,6 +217,10 @@ def parse_args():
     ap.add_argument("--no-color-affinity-leg", action="store_true",
                     help="N=1: skip the extra leg that measures colour-affinity seed routing against baseline striping with two domains on this GPU "
                          "(tools/color_affinity_probe.py, a child process)")
+    ap.add_argument("--affinity-nodes", type=int, default=2_000_000,
+                    help="N >= 2: nodes of the community graph of the colour-affinity leg (2 domains x N/2 ranks on the ranks of this job); 0 = skip")
+    ap.add_argument("--affinity-cache-mb", type=int, default=800, help="N >= 2: cache per DOMAIN in the colour-affinity leg (~10 %% of its table)")
+    ap.add_argument("--affinity-steps", type=int, default=300, help="N >= 2: steps per mode in the colour-affinity leg (0 = one epoch)")
     ap.add_argument("--no-fanout-leg", action="store_true", help="skip the extra fan-out 10,10 leg (BASELINE.json configs[2] batch shape)")
     ap.add_argument("--cold-tier", type=str, default="host", choices=["host", "shm", "hbm"],
                     help="host: pinned host memory (hipHostMalloc), zero-copy over PCIe (the workload BASELINE.json names). shm: the "
@@ -949,6 +953,13 @@ def _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, dev
     # N=1 only: the reference's distribution comparison (examples/Distribution_compare_script.sh:26-34) on one box -- two domains
     # x 1 rank on this GPU, real colours from the native colouring tool, node_color against baseline.  A child process: a failure
     # there is reported in the object and never costs the line.
+    if world >= 2 and world % 2 == 0 and args.mode == "minibatch" and not args.no_color_affinity_leg and args.affinity_nodes > 0:
+        fits, skipped = leg_fits("colour-affinity leg", 70.0)
+        if fits:
+            guard.arm(120.0, "colour-affinity leg (set-up)")
+            skipped = run_color_affinity_domains(args, world, rank, dev_index, device, single_dev, backend, guard)
+        if rank == 0:
+            line[f"color_affinity_2x{world // 2}"] = skipped
     if world == 1 and args.mode == "minibatch" and not args.no_color_affinity_leg:
         fits, skipped = leg_fits("colour-affinity leg", 60.0)
         guard.disarm()     # (a child process with a timeout of its own, inside what is left of the budget)
@@ -966,6 +977,112 @@ def _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, dev
         comm.destroy_process_group()
     elif args.rehearsal and dist.is_initialized():
         dist.destroy_process_group()
+
+
+def run_color_affinity_domains(args, world, rank, dev_index, device, single_dev, backend, guard):
+    """N >= 2: the reference's distribution comparison (examples/Distribution_compare_script.sh:26-34) ON the ranks of this job: the N
+    ranks form 2 domains of K = N/2 ranks (MPI_Comm_Manager(node = rank // K): a domain = the ranks that share one owner-partitioned
+    cache, node_distributor_pybind.cuh:150-222 routes every seed of the global batch to the domain whose cache holds most of its colour
+    neighbourhood), real colours from the native colouring tool on a graph with planted communities, `node_color` against `baseline`
+    over a bounded number of steps from a cold cache each, through the product's loader / distributor / scheduler / sampler / cache.
+    Rows of the first steps are checked bit-exact against the table and every global batch must be partitioned exactly, in both
+    modes.  -> dict (rank 0), None elsewhere."""
+    import tempfile
+    from COALA_GNN import COALA_GNN_DataLoader, MPI_Comm_Manager, Node_Distributor, SSD_INFO
+    from COALA_GNN.color_info_gen import color_graph, save_color_files
+    from COALA_GNN.sampler import NeighborSampler
+    from COALA_GNN.synthetic import PinnedFeatureTable, community_csc, feature_rows_torch, fill_table, fill_table_partition
+    K = world // 2
+    nodes, dim, batch = int(args.affinity_nodes), args.dim, args.batch
+    fan = [int(f) for f in args.fanout.split(",")]
+    t_leg = time.time()
+    comm = MPI_Comm_Manager(rank // K, backend="gloo" if single_dev else None)     # 2 domains x K ranks
+    comm.device_index = dev_index
+    be = "isolated" if K == 1 else backend                                           # one rank per domain: nothing to partition
+    comm.initialize_nested_process_group(be)
+    assert (comm.local_size, comm.num_master_process) == (K, 2)
+    indptr, indices = community_csc(nodes, args.avg_degree, 2048 if nodes >= 1_000_000 else 512, 0.9, seed=args.seed, device=device)
+    n_train = int(0.6 * nodes)
+    train_ids = torch.randperm(n_train, generator=torch.Generator().manual_seed(0))
+    steps_epoch = n_train // (batch * world) - 1
+    steps = min(steps_epoch, int(args.affinity_steps)) if args.affinity_steps > 0 else steps_epoch
+    # colours: once, by rank 0 (generate_color_data.py:11-68), handed to the others as the three .npy files the distributor reads
+    tmp = tempfile.mkdtemp(prefix="coala_bench_colors_") if rank == 0 else None
+    box = [tmp]
+    dist.broadcast_object_list(box, src=0)
+    tmp = box[0]
+    meta = [None]
+    if rank == 0:
+        t1 = time.time()
+        color, tk, sc, ncol, ncolored = color_graph(indptr.cpu().numpy(), indices.cpu().numpy(), np.arange(n_train, dtype=np.int64))
+        save_color_files(tmp, color, tk, sc)
+        meta = [{"num_colors": int(ncol), "colored_nodes": int(ncolored), "coloring_s": round(time.time() - t1, 2)}]
+        del color, tk, sc
+    dist.broadcast_object_list(meta, src=0)             # (also the barrier behind which the files exist)
+    files = [os.path.join(tmp, f) for f in ("color.npy", "topk.npy", "score.npy")]
+    cache_mb = max(16, int(args.affinity_cache_mb) // K)    # per rank: a domain holds affinity_cache_mb whatever K is
+    if K == 1:
+        table = PinnedFeatureTable(nodes, dim, dev_index)
+        fill_table(table.cpu_tensor, args.seed, device=device)
+    else:                                                # owner-partitioned inside the domain, as the headline run
+        table = PinnedFeatureTable((nodes + K - 1) // K, dim, dev_index)
+        fill_table_partition(table.cpu_tensor, args.seed, comm.local_rank, K, device=device)
+    res = {}
+    for mode in ("baseline", "node_color"):
+        guard.arm(90.0, f"colour-affinity leg ({mode})")
+        nd = Node_Distributor(comm, train_ids, batch, *files, parsing_method=mode)
+        smp = NeighborSampler(fan, seed=args.seed, bucket_by_owner=K if K > 1 else 0)   # the same sampler stream in both modes
+        g = smp.make_graph(indptr, indices)
+        loader = COALA_GNN_DataLoader(SSD_INFO(1, dim * 4, 1024, 0), nd, g, smp, batch, dim, fan, cache_mb, device, cache_backend=be,
+                                      sim_buf=table, num_rows=nodes, cold_partitioned=K > 1)
+        n_steps, verified, seen = 0, 0, []
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for input_nodes, seeds, blocks, feat in loader:
+            if n_steps < 3:
+                if not torch.equal(feat, feature_rows_torch(input_nodes, dim, args.seed)):
+                    raise RuntimeError(f"colour-affinity leg ({mode}): rank {rank} received rows that differ from the table at step {n_steps}")
+                verified += 1
+            seen.append(seeds.cpu())
+            n_steps += 1
+            if n_steps >= steps:
+                break
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t1
+        hit, miss, _ = loader.COALA_GNN_Manager.COALA_GNN_Cache.stats()
+        agg = loader.COALA_GNN_Manager.get_aggregate_time()
+        loader.close()
+        mine = {"domain": comm.master_process_index, "hit": int(hit), "miss": int(miss), "steps": n_steps, "verified": verified,
+                "fetch_ms": agg / max(n_steps, 1) * 1e3, "wall_ms": wall / max(n_steps, 1) * 1e3}
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        seeds_all = [None] * world
+        dist.all_gather_object(seeds_all, torch.cat(seen))
+        del loader, nd
+        if rank == 0:
+            union = torch.sort(torch.cat(seeds_all)).values
+            want = torch.sort(train_ids[: n_steps * batch * world]).values
+            dom = []
+            for d in range(2):
+                rs = [r for r in allr if r["domain"] == d]
+                dom.append({"hit_ratio": round(sum(r["hit"] for r in rs) / max(sum(r["hit"] + r["miss"] for r in rs), 1), 4),
+                            "fetch_ms_per_step": round(max(r["fetch_ms"] for r in rs), 4), "ranks": len(rs)})
+            res[mode] = {"per_domain": dom, "steps": n_steps,
+                         "hit_ratio_all_domains": round(sum(r["hit"] for r in allr) / max(sum(r["hit"] + r["miss"] for r in allr), 1), 4),
+                         "rows_bit_exact_steps_per_rank": min(r["verified"] for r in allr),
+                         "global_batches_partitioned_exactly": bool(torch.equal(union, want))}
+    table.close()
+    if rank != 0:
+        return None
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+    return {"what": f"colour-affinity seed routing vs baseline striping on the ranks of this job: 2 domains x {K} rank(s), "
+                    + ("an isolated cache per domain" if K == 1 else f"an owner-partitioned cache over {K} GPUs per domain") +
+                    ", each mode from a cold cache, same seeds and sampler stream",
+            "graph": "planted communities", "nodes": nodes, "edges": int(indices.numel()), "dim": dim, "cache_mb_per_domain": cache_mb * K,
+            "batch": batch, "fanout": args.fanout, **meta[0], **res,
+            "hit_ratio_delta": round(res["node_color"]["hit_ratio_all_domains"] - res["baseline"]["hit_ratio_all_domains"], 4),
+            "leg_seconds": round(time.time() - t_leg, 1)}
 
 
 def run_color_affinity_leg(timeout_s=400):
@@ -1291,8 +1408,30 @@ def run_cpu_baseline(args, host_array, batches, fanout, graph=None, seeds_for=No
                                            "what": "oracle/coala_oracle.c orc_gather_rows_mt: out[i] = table[idx[i]], one memcpy per row, rows dealt to "
                                                    "OpenMP threads in blocks of 64; thread count swept, best reported"}
             del out
+            # ... and what the CPU path delivers where the GPU path delivers it, in HBM: the same gather at its best thread count into a pinned
+            # staging buffer, then one host-to-device copy per minibatch, one after the other as `feat[input_nodes].to(device)` does
+            # (BASELINE.json configs[0]; examples/ssd_gnn_dataloader.py: CPU gather, then the copy)
+            if torch.cuda.is_available():
+                stage = torch.empty((max(len(x) for x in idx_host[:k]), args.dim), dtype=torch.float32, pin_memory=True)
+                stage_np = stage.numpy()
+                dev_out = torch.empty_like(stage, device="cuda")
+                O.gather_rows_mt(host_array, idx_host[0], stage_np, best)
+                dev_out.copy_(stage, non_blocking=True)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                r2 = 0
+                for ids in idx_host[:k]:
+                    O.gather_rows_mt(host_array, ids, stage_np, best)
+                    dev_out[: len(ids)].copy_(stage[: len(ids)], non_blocking=True)
+                    torch.cuda.synchronize()
+                    r2 += len(ids)
+                d2 = time.perf_counter() - t0
+                res["gather_openmp_memcpy"]["delivered_to_hbm"] = {
+                    "value": round(r2 * row_bytes / d2 / 1e9, 3), "unit": "GB/s", "threads": best, "ms_per_minibatch": round(d2 / k * 1e3, 3),
+                    "what": "the same gather into a pinned staging buffer + one H2D copy per minibatch, serially: rows in HBM per second, the quantity `value` of this line counts"}
+                del stage, dev_out
         except Exception as e:  # noqa: BLE001 -- a baseline leg never costs the line
-            res["gather_openmp_memcpy"] = {"error": repr(e)[:200]}
+            res.setdefault("gather_openmp_memcpy", {})["error"] = repr(e)[:200]
         # ---- torch.index_select over the same pinned table, thread count swept the same way
         try:
             t = torch.from_numpy(host_array)
@@ -1347,9 +1486,15 @@ def run_cpu_baseline(args, host_array, batches, fanout, graph=None, seeds_for=No
     steps_per_epoch = int(0.6 * args.rows) // args.batch - 1
     gathers = [ms_oracle] + [res[kk]["ms_per_minibatch"] for kk in ("gather_openmp_memcpy", "index_select_all_cores")
                              if isinstance(res.get(kk), dict) and res[kk].get("ms_per_minibatch")]
+    h2d = (res.get("gather_openmp_memcpy") or {}).get("delivered_to_hbm")
+    if h2d:
+        res["epoch_time_s_extrapolated_sampler_plus_gather_plus_h2d"] = None   # filled below
     samplers = [v for v in (res.get("sampler_twin_one_core_ms_per_minibatch"), (res.get("sampler_twin_all_cores") or {}).get("ms_per_minibatch")) if v]
     res["best_cpu_gather_ms_per_minibatch"] = round(min(gathers), 3)
     res["epoch_time_s_extrapolated_sampler_plus_gather"] = round(steps_per_epoch * (min(gathers) + (min(samplers) if samplers else 0.0)) / 1e3, 1)
+    if h2d:   # the like-for-like figure: sampled minibatches with their rows IN HBM, which is what the GPU path's epoch leg delivers
+        res["epoch_time_s_extrapolated_sampler_plus_gather_plus_h2d"] = round(
+            steps_per_epoch * (h2d["ms_per_minibatch"] + (min(samplers) if samplers else 0.0)) / 1e3, 1)
     return res
 
 

@@ -72,12 +72,20 @@ def test_bench_self_launch_two_ranks():
     process per GPU, started by the launcher)."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env["COALA_BENCH_SINGLE_DEVICE"] = "1"
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", *SMALL, "--no-fanout-leg"], capture_output=True, text=True,
-                         timeout=900, env=env)
+    small = [a for a in SMALL if a != "--no-color-affinity-leg"]
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", *small, "--no-fanout-leg", "--affinity-nodes", "150000",
+                          "--affinity-cache-mb", "16", "--affinity-steps", "40"], capture_output=True, text=True, timeout=900, env=env)
     d = _line(out)
     assert d["n_gpus"] == 2 and d["value"] > 0 and "error" not in d and d["config"]["TEST_HOOK_single_device"] is True
     assert d["epoch"]["serial"]["steps"] == 12
     assert "launcher: rank exit codes [0, 0]" in out.stderr
+    # f-3 on the ranks of the job (node_distributor_pybind.cuh:150-222): 2 domains x 1 rank, real colours, both modes bit-exact and exactly partitioned
+    ca = d["color_affinity_2x1"]
+    assert ca["num_colors"] > 10 and ca["baseline"]["steps"] == 40 and ca["node_color"]["steps"] == 40
+    for mode in ("baseline", "node_color"):
+        assert ca[mode]["rows_bit_exact_steps_per_rank"] == 3 and ca[mode]["global_batches_partitioned_exactly"] is True
+        assert len(ca[mode]["per_domain"]) == 2 and all(0 < x["hit_ratio"] < 1 and x["ranks"] == 1 for x in ca[mode]["per_domain"])
+    assert ca["node_color"]["hit_ratio_all_domains"] > ca["baseline"]["hit_ratio_all_domains"] - 0.01
 
 
 def test_bench_stall_ends_inside_the_time_budget():

@@ -269,6 +269,54 @@ def test_full_size_config2_counters_match_tag_only_oracle(hiplib, oracle, torch_
     table.close()
 
 
+def test_full_size_config1_products_shape(hiplib, oracle, torch_cuda):
+    """BASELINE configs[0] at its STATED size: ogbn-products shape, 2,449,029 x 100 fp32 (0.98 GB cold table; dim 100 < cache_dim 128: the
+    stride fix of SURVEY appendix A.2), fan-out 5,5 at bs 1024 through the native sampler on a products-shaped graph (average in-degree 25)
+    and COALA_GNN_Manager.fetch_feature (isolated, 128 MiB cache).  The reference runs this configuration on the CPU
+    (examples/ssd_gnn_dataloader.py:687-854, DGL sampler + feat[input_nodes]); the CPU side here is the tag-only oracle.  Properties: rows
+    bit-equal to the procedural table for every minibatch, hit / miss counters and the final tag table equal the oracle's, input nodes
+    unique with the seeds first, and a second pass over one minibatch is all hits with the same bytes."""
+    torch = torch_cuda
+    from COALA_GNN import MPI_Comm_Manager
+    from COALA_GNN.COALA_GNN_Manager import COALA_GNN_Manager
+    from COALA_GNN.sampler import NeighborSampler
+    from COALA_GNN.synthetic import alloc_pinned_table, feature_rows_torch, powerlaw_csc
+    rows, dim, cache_mb, batch, fan = 2_449_029, 100, 128, 1024, [5, 5]
+    table = alloc_pinned_table(rows, dim, seed=7, device=0)
+    indptr, indices = powerlaw_csc(rows, 25.0, seed=7, device="cuda")
+    sampler = NeighborSampler(fan, seed=7)
+    g = sampler.make_graph(indptr, indices)
+    comm = MPI_Comm_Manager(0)
+    comm.initialize_nested_process_group("isolated")
+    mgr = COALA_GNN_Manager(None, 1, dim * 4, 1024, 0, cache_mb, batch, fan, dim, comm, "cuda:0", cache_backend="isolated", sim_buf=table,
+                            num_rows=rows)
+    assert mgr.max_sample_size == 36864
+    geo = mgr.COALA_GNN_Cache.geometry()
+    assert (geo.cache_dim, geo.line_bytes, geo.num_sets) == (128, 512, oracle.num_sets(cache_mb, 128))
+    orc = oracle.OracleCache(cache_mb, dim, np.zeros((1, dim), dtype=np.float32), tag_only=True)
+    train = torch.randperm(int(0.6 * rows), generator=torch.Generator().manual_seed(7))
+    last = None
+    for step in range(40):
+        seeds = train[step * batch: (step + 1) * batch].cuda()
+        b = sampler.sample(g, seeds)
+        ids = b[0]
+        assert torch.equal(ids[:batch], seeds) and ids.unique().numel() == ids.numel() and ids.numel() <= mgr.max_sample_size
+        got = mgr.fetch_feature(b)[-1]
+        assert got.shape == (ids.numel(), dim) and torch.equal(got, feature_rows_torch(ids, dim, 7)), f"step {step}"
+        orc.read_feature(ids.cpu().numpy(), oracle.SCHED_HITS_FIRST, want_rows=False)
+        assert mgr.COALA_GNN_Cache.stats()[:2] == (orc.hit_cnt, orc.miss_cnt), f"step {step}"
+        last = b
+    assert orc.hit_cnt > 0 and orc.miss_cnt > 0
+    keys, cnt, _ = mgr.COALA_GNN_Cache.dump()
+    assert np.array_equal(keys, orc.keys()) and np.array_equal(cnt, orc.set_cnt())
+    hit0 = mgr.COALA_GNN_Cache.stats()[0]
+    again = mgr.fetch_feature(last)[-1]
+    assert torch.equal(again, feature_rows_torch(last[0], dim, 7))
+    assert mgr.COALA_GNN_Cache.stats()[0] - hit0 >= int(0.999 * last[0].numel())    # (a set keeps 32 lines: a batch overflows one at most by a handful)
+    del mgr
+    table.close()
+
+
 @pytest.mark.parametrize("name,dim,cache_mb,n,num_rows", [
     ("papers100M 15,10,5 (config 4)", 128, 16384, 1024 * 16 * 11 * 6, 24_000_000),    # 1,081,344 rows per minibatch
     ("IGB-large 10,10,10 (config 5)", 1024, 16384, 1024 * 11 * 11 * 11, 4_000_000),     # 1,362,944 rows = 5.58 GB out

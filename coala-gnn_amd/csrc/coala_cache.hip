@@ -224,8 +224,17 @@ template <typename V> __device__ __forceinline__ void k1_store(V v, V* p) {
 // chunks, which is what the software pipeline's registers are for (4-KiB lines: 76 instead of 110 VGPRs, 6 instead of 4 waves per SIMD) and
 // whose id / tag loads a one-chunk wave issues for chunks it never has.  The product's choice for lines of 1 KiB and more; 512-B lines keep
 // the looping kernel (8-row waves gain from the pipeline whenever a wave does run two chunks, and lose nothing when it does not).
+// Round 4, the last K1 experiment (profiles/r04_k1_min_waves.txt): on 512-B lines the looping kernel needs 66 VGPRs = 7 waves per SIMD; bounded to 8
+// waves (-DK1_MIN_WAVES_SHORT=8) the configs[3] variant fits 64 registers without a spill -- and is no faster in the product's block shape: 11.3 against
+// 11.4 us at ~72 k rows, 44-48 against 49 us at ~289 k (the development build's 256-thread blocks gained 7 % at 72 k rows).  Not adopted.
+#ifndef K1_MIN_WAVES_SHORT
+#define K1_MIN_WAVES_SHORT K1_MIN_WAVES
+#endif
+template <int CD, typename TAG, bool FULL, bool REDIR> constexpr int k1_min_waves() {
+    return (CD <= 128 && sizeof(TAG) == 4 && FULL && !REDIR) ? K1_MIN_WAVES_SHORT : K1_MIN_WAVES;
+}
 template <int CD, int VEC, typename TAG, int NP = 4, bool FULL = false, int NOMISS = 0, bool REDIR = false, bool SINGLE = false>
-__global__ __launch_bounds__(64 * kK1MaxWaves, K1_MIN_WAVES) void probe_gather_kernel(const int64_t* __restrict__ idx, float* __restrict__ out,
+__global__ __launch_bounds__(64 * kK1MaxWaves, (k1_min_waves<CD, TAG, FULL, REDIR>())) void probe_gather_kernel(const int64_t* __restrict__ idx, float* __restrict__ out,
                                                                     int64_t n, uint32_t gen, uint32_t n_blocks, CacheDev c, Redirect rd) {
     // Argument order and the explicit block count are deliberate: with kernarg preloading (build.py: -mllvm -amdgpu-kernarg-preload-count=16)
     // the leading scalar arguments arrive in SGPRs, and with the compile-time block shape the first id load needs nothing from

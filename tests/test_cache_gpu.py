@@ -275,7 +275,7 @@ def test_full_size_config1_products_shape(hiplib, oracle, torch_cuda):
     and COALA_GNN_Manager.fetch_feature (isolated, 128 MiB cache).  The reference runs this configuration on the CPU
     (examples/ssd_gnn_dataloader.py:687-854, DGL sampler + feat[input_nodes]); the CPU side here is the tag-only oracle.  Properties: rows
     bit-equal to the procedural table for every minibatch, hit / miss counters and the final tag table equal the oracle's, input nodes
-    unique with the seeds first, and a second pass over one minibatch is all hits with the same bytes."""
+    unique with the seeds first, and a second pass over one minibatch delivers the same bytes with the oracle's hit count (nearly all hits)."""
     torch = torch_cuda
     from COALA_GNN import MPI_Comm_Manager
     from COALA_GNN.COALA_GNN_Manager import COALA_GNN_Manager
@@ -312,7 +312,10 @@ def test_full_size_config1_products_shape(hiplib, oracle, torch_cuda):
     hit0 = mgr.COALA_GNN_Cache.stats()[0]
     again = mgr.fetch_feature(last)[-1]
     assert torch.equal(again, feature_rows_torch(last[0], dim, 7))
-    assert mgr.COALA_GNN_Cache.stats()[0] - hit0 >= int(0.999 * last[0].numel())    # (a set keeps 32 lines: a batch overflows one at most by a handful)
+    orc.read_feature(last[0].cpu().numpy(), oracle.SCHED_HITS_FIRST, want_rows=False)
+    assert mgr.COALA_GNN_Cache.stats()[:2] == (orc.hit_cnt, orc.miss_cnt)
+    # almost all hits -- not all: round-robin eviction does not spare a line that was hit earlier in the same batch (isolated_cache.h:197-210)
+    assert mgr.COALA_GNN_Cache.stats()[0] - hit0 >= int(0.9 * last[0].numel())
     del mgr
     table.close()
 

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Wave-scheduler and L2 counters of K1 in situ (rocprofv3 --pmc, separate passes): how long does a wave live, how much of that is it parked at a
 # wait, how many waves are resident, what does the L2 say.  Usage on the GPU box:  [ROWS=.. DIM=.. FANOUT=.. CACHE_MB=.. DEG=..] bash tools/k1_sq_counters.sh <tag>
+# HARNESS=tools/kernel_sq_probe.py: the same passes over the wide-grid cold fill (cold tier in HBM) and the un-permute kernel (SC below).
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$PWD}
 TAG=${1:-papers100m}
@@ -14,7 +15,7 @@ i=0
 for P in "$P1" "$P2" "$P3" "$P4"; do
   i=$((i + 1))
   mkdir -p $R/gpurun_out/sq_${TAG}_$i
-  timeout -k 10 400 rocprofv3 --pmc $P --output-format csv -d $R/gpurun_out/sq_${TAG}_$i -- python3 $R/tools/k1_insitu.py "" > $R/gpurun_out/sq_${TAG}_$i.log 2>&1
+  timeout -k 10 400 rocprofv3 --pmc $P --output-format csv -d $R/gpurun_out/sq_${TAG}_$i -- python3 $R/${HARNESS:-tools/k1_insitu.py} "" > $R/gpurun_out/sq_${TAG}_$i.log 2>&1
   echo "pass $i rc=$?"
 done
 cd $R
@@ -29,13 +30,13 @@ for i in (1, 2, 3, 4):
         # steady state only: the last 200 launches of each kernel (the first 420 are warm-up minibatches with fewer hits)
         by = collections.defaultdict(list)
         for r in rows:
-            k = "K1" if "probe_gather_kernel" in r["Kernel_Name"] else ("K2" if "miss_fill_kernel" in r["Kernel_Name"] else None)
+            k = "K1" if "probe_gather_kernel" in r["Kernel_Name"] else ("K2" if "miss_fill_kernel" in r["Kernel_Name"] else ("SC" if "scatter_rows_kernel" in r["Kernel_Name"] else None))
             if k:
                 by[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
         for (k, c), v in by.items():
             v = v[-200:]
             tot[k][c] = sum(v) / len(v)
-for k in ("K1", "K2"):
+for k in ("K1", "K2", "SC"):
     print(f"--- {k}: per launch, mean of the last 200 launches")
     for c, v in sorted(tot[k].items()):
         print(f"  {c:24s} {v:16.1f}")

@@ -130,7 +130,11 @@ int coala_cache_serve_abort(coala_cache_t* h, void* stream);
  * out[pos, 0:dim], by the probe and by every later fill of the batch.  This is how the requester's OWN shard of a
  * distributed fetch goes straight into the caller's tensor (the reference's `j == i` local copy,
  * COALA-GNN-Setup/COALA_GNN/COALA_GNN_Manager.py:195-199) while staying part of the owner's one batch per step.
- * `out` may be NULL when the redirect covers the whole batch. */
+ * `out` may be NULL when the redirect covers the whole batch.
+ * Every row_map entry must lie in [0, 2^31): the probe carries a row's destination as a 32-bit value (a batch never has more
+ * rows than that: n <= 2^31 - 1 is checked).  The entries live in device memory, so the library cannot check them on the host: a
+ * value outside that range addresses the wrong row.  The library's own caller (coala_cache_fetch_distributed) passes positions
+ * of the batch, which are below n by construction. */
 typedef struct coala_row_redirect {
     int64_t begin, end;
     float* out;

@@ -5,7 +5,7 @@
 # so the queue count it reports has to be exported by the shell that starts the profiler
 export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-8}
 R=${GRAFT_REPO_ROOT:-$PWD}
-export ROUND=${ROUND:-r03} TMPDIR=/tmp
+export ROUND=${ROUND:-r04} TMPDIR=/tmp
 O=$R/gpurun_out/profiles_out
 mkdir -p $O
 cd $R

@@ -9,7 +9,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = os.environ.get("ROUND", "r03")
+ROUND = os.environ.get("ROUND", "r04")
 OUR = ("probe_gather_kernel", "miss_fill_kernel", "scatter_rows_kernel", "route_", "sample_insert_kernel", "scan_assign_kernel", "relabel_clear_kernel",
        "bucket_", "mean_aggregate")  # the product's kernels (torch has kernels in anonymous namespaces too)
 

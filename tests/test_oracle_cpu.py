@@ -165,3 +165,16 @@ def test_sampler_twin_is_thread_count_independent(oracle, golden, threads):
     seeds = rng.integers(-2, n + 2, size=700).astype(np.int64)       # duplicates, -1/-2 and n, n+1 (rejected: rows of -1)
     for a, b in zip(oracle.sample_blocks(ip, ix, seeds, [7, 3], 9, 2), oracle.sample_blocks(ip, ix, seeds, [7, 3], 9, 2, threads=threads)):
         assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+@pytest.mark.parametrize("threads", [1, 3, 8])
+def test_openmp_row_gather_is_a_gather(oracle, threads):
+    """orc_gather_rows_mt (bench.py's cpu_baseline leg only): out[i] = table[idx[i]] for any thread count, duplicates and an empty batch included."""
+    rng = np.random.default_rng(3)
+    table = rng.random((5000, 100), dtype=np.float32)
+    idx = rng.integers(0, 5000, size=3333).astype(np.int64)
+    out = np.full((4000, 100), -1.0, dtype=np.float32)
+    used = oracle.gather_rows_mt(table, idx, out, threads)
+    assert 1 <= used <= threads
+    assert out[:3333].tobytes() == table[idx].tobytes() and (out[3333:] == -1.0).all()
+    assert oracle.gather_rows_mt(table, idx[:0], out, threads) >= 1 and out[:3333].tobytes() == table[idx].tobytes()

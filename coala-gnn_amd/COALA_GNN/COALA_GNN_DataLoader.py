@@ -34,21 +34,24 @@ def _loader_streams(device):
 
 
 class _NativeEvent(object):
-    """The end event a fetch carries on its last kernel dispatch (COALA_GNN_Manager.last_done_event): same two uses as a torch event."""
-    __slots__ = ("handle",)
+    """The end event(s) a fetch carries on its own launches (COALA_GNN_Manager.last_done_event: one handle, or one per stream of a
+    distributed fetch): same two uses as a torch event."""
+    __slots__ = ("handles",)
 
-    def __init__(self, handle):
-        self.handle = handle
+    def __init__(self, handles):
+        self.handles = tuple(handles) if isinstance(handles, (tuple, list)) else (handles,)
 
     def synchronize(self):
         from COALA_GNN_Pybind import event_elapsed_ms
-        event_elapsed_ms(self.handle, self.handle, wait=True)
+        for h in self.handles:
+            event_elapsed_ms(h, h, wait=True)
 
 
 def _wait_for(stream, ev):
     if isinstance(ev, _NativeEvent):
         from COALA_GNN_Pybind import stream_wait_event
-        stream_wait_event(ev.handle, int(stream.cuda_stream))
+        for h in ev.handles:
+            stream_wait_event(h, int(stream.cuda_stream))
     else:
         stream.wait_event(ev)
 
@@ -289,6 +292,8 @@ class COALA_GNN_DataLoader(torch.utils.data.DataLoader):
         """The event that marks the rows of the fetch just enqueued complete: the one its last kernel carries, when the manager has
         one (no packet of its own in the fetch stream's queue), else an event recorded behind it."""
         nat = getattr(self.COALA_GNN_Manager, "last_done_event", None)
+        if isinstance(nat, torch.cuda.Event):
+            return nat                       # (the manager had to record one itself: reuse it)
         if nat:
             return _NativeEvent(nat)
         ev = torch.cuda.Event()

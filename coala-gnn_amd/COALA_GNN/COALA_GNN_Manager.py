@@ -309,6 +309,17 @@ class NativeExchange(object):
     def rounds(self, k):  # must be set to the same value on every rank, between fetches
         self._capi.check(self._lib.coala_comm_set_rounds(self._h, int(k)))
 
+    def fetch_events(self, enable=True):
+        """coala_comm_fetch_events: a bucketed fetch carries its begin / end events on its own launches (no packets of theirs on the caller's stream)."""
+        self._capi.check(self._lib.coala_comm_fetch_events(self._h, 1 if enable else 0))
+
+    def last_fetch_events(self):
+        """(begin, end on the caller's stream, end on the communicator's stream) of the most recent fetch as native handles; None where there is none."""
+        C = self._C
+        a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._capi.check(self._lib.coala_comm_last_fetch_events(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
     def set_self_loopback(self, on):
         """Diagnostics (coala_comm_set_self_loopback): the own segment takes the road of a peer's, through the transport itself."""
         self._capi.check(self._lib.coala_comm_set_self_loopback(self._h, 1 if on else 0))
@@ -391,6 +402,14 @@ class NativeExchange(object):
             pass
 
 
+def owner_counts_present(mgr, batch):
+    """Will fetch_feature take the bucketed road for this batch (the sampler delivered the input nodes bucketed by owner)?"""
+    if mgr.exchange is None or not hasattr(mgr.exchange, "fetch_bucketed") or len(batch) < 3 or not batch[2]:
+        return False
+    oc = getattr(batch[2][0], "owner_counts", None)
+    return oc is not None and oc.numel() == mgr.MPI_comm_manager.local_size and batch[2][0].src_nodes is batch[0]
+
+
 class COALA_GNN_Manager(object):
     def __init__(self, node_distributor, num_ssds, page_size, num_elems, ssd_read_offset, cache_size,  # MB
                  batch_size, fan_out, dim, MPI_comm_manager, device, cache_backend="nvshmem", sim_buf=None,
@@ -410,9 +429,11 @@ class COALA_GNN_Manager(object):
         # Stream-ordered mode, isolated backend: the begin / end events of a fetch ride on its two kernel dispatches
         # (coala_cache_fetch_events) instead of being recorded as packets of their own -- on a stream that carries nothing but
         # fetches, every extra packet between the cold fill of one minibatch and the probe of the next is 6-12 us of idle link.
-        # last_done_event: the native end event of the most recent fetch (None: the caller records one itself).
+        # The same for the native exchange's bucketed fetch (coala_comm_fetch_events): begin on the probe, one end event per stream.
+        # last_done_event: the native end event(s) of the most recent fetch -- a handle or a tuple of handles (None: the caller records one itself).
         self.last_done_event = None
         self._native_events = False
+        self._native_exchange_events = False
         if not self.is_simulation:
             raise RuntimeError("sim_buf is None: the NVMe/BaM tier is out of scope here; pass the pinned feature table "
                                "(the reference's --feat_cpu mode, used by every published script)")
@@ -473,6 +494,9 @@ class COALA_GNN_Manager(object):
                 self.exchange = make_exchange()
         else:
             raise ValueError(f"Unsupported cache backend: {self.cache_backend}")  # the reference prints and returns (:113-115)
+        if isinstance(self.exchange, NativeExchange) and not profile:
+            self.exchange.fetch_events(True)
+            self._native_exchange_events = True
 
     def fetch_feature(self, batch):  # :118-213
         index = batch[0].to(self.device)
@@ -484,7 +508,8 @@ class COALA_GNN_Manager(object):
         fetch_start = time.time()
         ev_pair = None
         self.last_done_event = None
-        native_ev = (not self.sync_on_return) and self._native_events and index_size > 0
+        native_ev = (not self.sync_on_return) and index_size > 0 and (
+            self._native_events or (self._native_exchange_events and owner_counts_present(self, batch)))
         if not self.sync_on_return and not native_ev:
             ev_pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev_pair[0].record()
@@ -525,10 +550,20 @@ class COALA_GNN_Manager(object):
             torch.cuda.current_stream().synchronize()
             self.aggregation_timer += (time.time() - fetch_start)
         elif native_ev:
-            a, b = self.COALA_GNN_Cache.last_fetch_events()
-            if b:
-                self.last_done_event = b
-                self._agg_events.append((a, b))
+            if self._native_events:
+                a, b = self.COALA_GNN_Cache.last_fetch_events()
+                if b:
+                    self.last_done_event = b
+                    self._agg_events.append((a, b))
+            else:
+                a, b_st, b_cs = self.exchange.last_fetch_events()
+                if b_st:
+                    self.last_done_event = (b_st, b_cs) if b_cs else b_st
+                    self._agg_events.append((a, b_cs or b_st))
+            if self.last_done_event is None:     # (a profiling cache handle, a routed fetch: nothing rode on the launches)
+                ev = torch.cuda.Event()
+                ev.record()
+                self.last_done_event = ev
             if len(self._agg_events) >= 64 and (len(self._agg_events) % 64 == 0 or len(self._agg_events) >= 1024):
                 # (the handle keeps 2048 pairs: a host that runs far ahead of the device waits here, at 1024 unread ones)
                 self._fold_events(wait=len(self._agg_events) >= 1024)

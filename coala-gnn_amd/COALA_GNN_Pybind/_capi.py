@@ -81,6 +81,8 @@ SYMBOLS = {
     "coala_comm_set_rounds": (_I, [_VP, _I]),
     "coala_comm_get_rounds": (_I, [_VP]),
     "coala_comm_set_self_loopback": (_I, [_VP, _I]),
+    "coala_comm_fetch_events": (_I, [_VP, _I]),
+    "coala_comm_last_fetch_events": (_I, [_VP, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(_VP)]),
     "coala_comm_profile": (_I, [_VP, _I, C.POINTER(CommProfile), _I]),
     "coala_comm_last_counts": (_I, [_VP, _VP, _VP]),
     "coala_cache_fetch_distributed": (_I, [_VP, _VP, _VP, _VP, _I64, _VP]),

@@ -1199,9 +1199,14 @@ int coala_cache_geometry(const coala_cache_t* h, coala_cache_geometry_t* out) {
 
 enum { kPhaseProbe = 1, kPhaseFill = 2, kPhaseBoth = 3 };
 
+// ext_begin / ext_end (library-internal callers: the distributed fetch): events to put ON the probe's launch (its begin) / on the LAST fill
+// launch of this call (its end) instead of recording them behind it; *attached says which of the two found a launch to ride on (bit 0 / bit 1) --
+// a profiling handle uses the dispatches' event slots itself, a call may launch nothing -- so that the caller records the others the plain way.
 static int read_feature_impl(coala_cache_t* h, float* out, const int64_t* idx, int64_t n, void* stream, bool force_dist,
                              int phases, const int64_t* begins, const int64_t* ends, int n_ranges,
-                             const coala_row_redirect_t* redirect) {
+                             const coala_row_redirect_t* redirect, hipEvent_t ext_begin = nullptr, hipEvent_t ext_end = nullptr,
+                             int* attached = nullptr) {
+    if (attached) *attached = 0;
     if (!h) return fail(COALA_EINVAL, "null handle");
     h->last_begin = h->last_end = nullptr; // (set again below when this call launches a whole read with its events attached)
     if (n < 0 || n > 0x7FFFFFFFll) return fail(COALA_EINVAL, "n=%lld out of range", (long long)n);
@@ -1283,6 +1288,17 @@ static int read_feature_impl(coala_cache_t* h, float* out, const int64_t* idx, i
         fe_begin = h->fev[2 * slot];
         fe_end = h->fev[2 * slot + 1];
     }
+    const bool own_ring = fe_begin != nullptr;
+    if (!own_ring && !(h->cfg.flags & COALA_FLAG_PROFILE)) {
+        fe_begin = (phases & kPhaseProbe) ? ext_begin : nullptr;
+        fe_end = (phases & kPhaseFill) ? ext_end : nullptr;
+    }
+    int n_sets = 0, set_no = 0;   // fill launches of this call (one per 64 ranges): the end event rides on the last one
+    if ((phases & kPhaseFill) && fill_rows > 0) {
+        int live = 0;
+        for (int k = 0; k < n_ranges; ++k) live += ends[k] > begins[k];
+        n_sets = (live + kMaxRanges - 1) / kMaxRanges;
+    }
     rc = dispatch_geo(d.cache_dim, vec4, [&](auto geo) -> int {
         constexpr int CD = geo_cd(geo);
         constexpr int VEC = geo_vec(geo);
@@ -1335,7 +1351,7 @@ static int read_feature_impl(coala_cache_t* h, float* out, const int64_t* idx, i
             // verdict tile: 64 rows behind the narrow host-tier grid, one chunk behind the wide HBM-tier grid (see the kernel)
             const int tile_rows = h->k2_tile_rows > 0 ? h->k2_tile_rows : G::R;
             return for_each_range_set(begins, ends, n_ranges, [&](const RangeSet& rs) -> int {
-                ProfScope ps(h, s, 2, 0, nullptr, fe_end);
+                ProfScope ps(h, s, 2, 0, nullptr, (++set_no == n_sets) ? fe_end : nullptr);
                 const int64_t tiles = ((int64_t)rs.total + tile_rows - 1) / tile_rows;
                 const dim3 grid(grid_for(tiles, 4, h->k2_grid_cap));
                 if (redir) ps.launch(miss_fill_kernel<CD, VEC, true>, grid, dim3(256), d, idx, out, tile_rows, h->k2_sparse_max, gen, rs, rd);
@@ -1346,10 +1362,12 @@ static int read_feature_impl(coala_cache_t* h, float* out, const int64_t* idx, i
         return COALA_OK;
     });
     if (rc) return rc;
-    if (fe_begin) {
+    if (own_ring) {
         h->last_begin = fe_begin;
         h->last_end = fe_end;
         h->fev_calls++;
+    } else if (attached) {
+        *attached = ((fe_begin && (phases & kPhaseProbe)) ? 1 : 0) | ((fe_end && n_sets > 0) ? 2 : 0);
     }
     if (phases & kPhaseProbe) h->rows_total += (uint64_t)n;
     if (phases == kPhaseFill) {
@@ -1380,6 +1398,16 @@ int coala_cache_serve_probe(coala_cache_t* h, float* out, const int64_t* ids, in
 int coala_cache_serve_probe_redirect(coala_cache_t* h, float* out, const int64_t* ids, int64_t n, const coala_row_redirect_t* redirect,
                                      void* stream) {
     return read_feature_impl(h, out, ids, n, stream, true, kPhaseProbe, nullptr, nullptr, 0, redirect);
+}
+
+// library-internal (coala_internal.h): the split-phase serve with events on its launches
+int coala_serve_probe_redirect_ev_(coala_cache_t* h, float* out, const int64_t* ids, int64_t n, const coala_row_redirect_t* redirect, void* stream,
+                                   hipEvent_t begin_ev, int* attached) {
+    return read_feature_impl(h, out, ids, n, stream, true, kPhaseProbe, nullptr, nullptr, 0, redirect, begin_ev, nullptr, attached);
+}
+int coala_serve_fill_ranges_ev_(coala_cache_t* h, float* out, const int64_t* ids, int64_t n, const int64_t* begins, const int64_t* ends, int n_ranges,
+                                void* stream, hipEvent_t end_ev, int* attached) {
+    return read_feature_impl(h, out, ids, n, stream, true, kPhaseFill, begins, ends, n_ranges, nullptr, nullptr, end_ev, attached);
 }
 
 int coala_cache_serve_fill(coala_cache_t* h, float* out, const int64_t* ids, int64_t n, int64_t begin, int64_t end, void* stream) {

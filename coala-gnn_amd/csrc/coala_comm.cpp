@@ -284,6 +284,14 @@ struct coala_comm {
     coala_comm_profile_t prof{};
     bool broken = false;
     bool loopback = false;          // coala_comm_set_self_loopback
+    // coala_comm_fetch_events: begin / end events of a bucketed fetch without packets of their own on the caller's stream; a ring of triples
+    // (begin on the probe's launch, end on the last fill launch of the caller's stream, end behind the last row round on the communicator's stream)
+    bool fetch_events = false;
+    bool plain_events = false;      // development builds, COALA_COMM_PLAIN_EVENTS=1: every event recorded behind its kernel, every round waited for (the round-3 form; tools/dist_packets_probe.py)
+    static constexpr int kFetchRing = 2048;
+    std::vector<hipEvent_t> fev;    // [3 * kFetchRing], created on first use
+    uint64_t fev_calls = 0;
+    hipEvent_t last_ev[3] = {nullptr, nullptr, nullptr};
     // count exchanges issued ahead of their fetch (coala_comm_counts_begin): ring of device [2G] + pinned [2G] + event
     static constexpr int kCountsRing = COALA_COUNTS_RING;
     int64_t* ahead_dev = nullptr;   // [kCountsRing][2G]
@@ -307,6 +315,9 @@ int finish_create(coala_comm* c) {
         const int r = atoi(e);
         if (r >= 1 && r <= kMaxRounds) c->rounds = r;
     }
+#ifdef COALA_DEV_KNOBS
+    if (const char* e = getenv("COALA_COMM_PLAIN_EVENTS")) c->plain_events = atoi(e) != 0;
+#endif
     // The communication stream gets the highest stream priority: HIP keeps priority levels on separate hardware queues, so the row
     // exchange can never be queued behind the cold fill it is meant to run beside (with equal priorities the streams of a process
     // share GPU_MAX_HW_QUEUES = 4 queues in creation order), and its few workgroups are scheduled ahead of the fill's.
@@ -498,6 +509,8 @@ int coala_comm_destroy(coala_comm_t* c) {
     }
     if (c->cs) (void)hipStreamDestroy(c->cs);
     if (c->order_ev) (void)hipEventDestroy(c->order_ev);
+    for (auto e : c->fev)
+        if (e) (void)hipEventDestroy(e);
     for (int k = 0; k < coala_comm::kCountsRing; ++k)
         if (c->ahead_ev[k]) (void)hipEventDestroy(c->ahead_ev[k]);
     if (c->ahead_host) (void)hipHostFree(c->ahead_host);
@@ -518,6 +531,21 @@ int coala_comm_set_rounds(coala_comm_t* c, int rounds) {
 }
 
 int coala_comm_get_rounds(const coala_comm_t* c) { return c ? c->rounds : 0; }
+
+int coala_comm_fetch_events(coala_comm_t* c, int enable) {
+    if (!c) return fail(COALA_EINVAL, "null communicator");
+    c->fetch_events = enable != 0;
+    if (!c->fetch_events) c->last_ev[0] = c->last_ev[1] = c->last_ev[2] = nullptr;
+    return COALA_OK;
+}
+
+int coala_comm_last_fetch_events(const coala_comm_t* c, void** begin_ev, void** end_ev_stream, void** end_ev_comm) {
+    if (!c) return fail(COALA_EINVAL, "null communicator");
+    if (begin_ev) *begin_ev = (void*)c->last_ev[0];
+    if (end_ev_stream) *end_ev_stream = (void*)c->last_ev[1];
+    if (end_ev_comm) *end_ev_comm = (void*)c->last_ev[2];
+    return COALA_OK;
+}
 
 int coala_comm_set_self_loopback(coala_comm_t* c, int on) {
     if (!c || !c->tr) return fail(COALA_EINVAL, "null communicator");
@@ -607,6 +635,7 @@ int coala_cache_fetch_distributed_bucketed_ahead(coala_cache_t* h, coala_comm_t*
 static int fetch_impl(coala_cache_t* h, coala_comm_t* c, float* out, const int64_t* idx, int64_t n, const int64_t* bucket_counts_dev,
                       const int64_t* counts_host, void* stream) {
     if (!h || !c) return fail(COALA_EINVAL, "null handle");
+    c->last_ev[0] = c->last_ev[1] = c->last_ev[2] = nullptr;
     const bool bucketed = bucket_counts_dev != nullptr;
     if (c->broken) return fail(COALA_ECOMM, "this communicator failed in an earlier fetch and was aborted: destroy it");
     // every check that can fail locally comes BEFORE the first collective: a rank that returns between collectives strands its peers
@@ -688,7 +717,23 @@ static int fetch_impl(coala_cache_t* h, coala_comm_t* c, float* out, const int64
     rd.end = loop ? rd.begin : (int64_t)(rdis[me] + rcnt[me]);
     rd.out = bucketed ? out + sdis[me] * (size_t)dim : out; // bucketed: the own bucket sits at its offset, in order
     rd.row_map = bucketed ? nullptr : c->map + sdis[me];
-    if ((rc = coala_cache_serve_probe_redirect(h, c->rows_send, c->recv_ids, (int64_t)total_recv, &rd, st))) return broke(rc);
+    // Events of this fetch.  Every hipEventRecord on the caller's stream is one more barrier packet between the kernels of a saturated
+    // stream (6-12 us each: DESIGN.md section 6), so whatever can ride ON a launch does: the hand-over events of the fill rounds always, and
+    // -- opt-in, bucketed fetches: coala_comm_fetch_events -- the begin / end events a caller needs for timing and for its consumer's stream.
+    const bool ev_mode = c->fetch_events && bucketed && n > 0 && !c->plain_events;
+    hipEvent_t ev_begin = nullptr, ev_end_st = nullptr, ev_end_cs = nullptr;
+    if (ev_mode) {
+        if (c->fev.empty()) c->fev.assign(3 * (size_t)coala_comm::kFetchRing, nullptr);
+        const size_t slot = (size_t)(c->fev_calls % coala_comm::kFetchRing);
+        for (size_t k = 3 * slot; k < 3 * slot + 3; ++k)
+            if (!c->fev[k] && hipEventCreate(&c->fev[k]) != hipSuccess) return broke(fail(COALA_EHIP, "hipEventCreate failed"));
+        ev_begin = c->fev[3 * slot];
+        ev_end_st = c->fev[3 * slot + 1];
+        ev_end_cs = c->fev[3 * slot + 2];
+    }
+    int att = 0;
+    if ((rc = coala_serve_probe_redirect_ev_(h, c->rows_send, c->recv_ids, (int64_t)total_recv, &rd, st, c->plain_events ? nullptr : ev_begin, &att))) return broke(rc);
+    if (ev_begin && !(att & 1) && hipEventRecord(ev_begin, st) != hipSuccess) return broke(fail(COALA_EHIP, "hipEventRecord failed"));
     // 6. rounds: fill slice k of every peer's segment on the caller's stream, ship it on the comm stream while slice k+1 fills
     const int K = (G == 1 && !loop) ? 1 : c->rounds;
     const bool exchange_rows = G > 1 || loop;
@@ -696,6 +741,7 @@ static int fetch_impl(coala_cache_t* h, coala_comm_t* c, float* out, const int64
     std::vector<int64_t> fb(G), fe(G);
     std::vector<size_t> xs_cnt(G), xs_dis(G), xr_cnt(G), xr_dis(G);
     std::vector<int64_t> sb((size_t)G * K), se((size_t)G * K); // requester-side ranges of rows_recv, per round
+    hipEvent_t fill_evs[kMaxRounds] = {};
     hipEvent_t t0 = nullptr, t1 = nullptr;
     if (c->profile && exchange_rows) {
         if (c->prof_live.size() >= 4096) drain_profile(c);
@@ -716,12 +762,19 @@ static int fetch_impl(coala_cache_t* h, coala_comm_t* c, float* out, const int64
             }
             if (e > b) { fb[nr] = b; fe[nr] = e; ++nr; }
         }
-        if ((rc = coala_cache_serve_fill_ranges(h, c->rows_send, c->recv_ids, (int64_t)total_recv, fb.data(), fe.data(), nr, st))) return broke(rc);
-        if (exchange_rows && hipEventRecord(c->ev_fill[k], st) != hipSuccess) return broke(fail(COALA_EHIP, "hipEventRecord failed"));
+        // the event the row round k waits for rides on this round's fill launch; the last round's is the fetch's end event on this stream
+        const bool last = k == K - 1;
+        hipEvent_t fill_ev = (last && ev_end_st) ? ev_end_st : (exchange_rows ? c->ev_fill[k] : nullptr);
+        fill_evs[k] = fill_ev;
+        if ((rc = coala_serve_fill_ranges_ev_(h, c->rows_send, c->recv_ids, (int64_t)total_recv, fb.data(), fe.data(), nr, st, c->plain_events ? nullptr : fill_ev, &att))) return broke(rc);
+        if (fill_ev && !(att & 2) && hipEventRecord(fill_ev, st) != hipSuccess) return broke(fail(COALA_EHIP, "hipEventRecord failed"));
     }
-    if (total_recv == 0 && exchange_rows) // nothing to serve: the rounds below still run (peers may owe this rank rows)
-        for (int k = 0; k < K; ++k)
-            if (hipEventRecord(c->ev_fill[k], st) != hipSuccess) return broke(fail(COALA_EHIP, "hipEventRecord failed"));
+    if (total_recv == 0) // nothing to serve: the rounds below still run (peers may owe this rank rows)
+        for (int k = 0; k < K; ++k) {
+            fill_evs[k] = (k == K - 1 && ev_end_st) ? ev_end_st : (exchange_rows ? c->ev_fill[k] : nullptr);
+            if (fill_evs[k] && hipEventRecord(fill_evs[k], st) != hipSuccess) return broke(fail(COALA_EHIP, "hipEventRecord failed"));
+        }
+    hipEvent_t x_evs[kMaxRounds] = {};
     if (exchange_rows) {
         for (int k = 0; k < K; ++k) {
             for (int p = 0; p < G; ++p) {
@@ -735,11 +788,12 @@ static int fetch_impl(coala_cache_t* h, coala_comm_t* c, float* out, const int64
                 sb[(size_t)k * G + p] = (int64_t)(sdis[p] + u);
                 se[(size_t)k * G + p] = skip ? (int64_t)(sdis[p] + u) : (int64_t)(sdis[p] + v);
             }
-            if (hipStreamWaitEvent(c->cs, c->ev_fill[k], 0) != hipSuccess) return broke(fail(COALA_EHIP, "hipStreamWaitEvent failed"));
+            if (hipStreamWaitEvent(c->cs, fill_evs[k], 0) != hipSuccess) return broke(fail(COALA_EHIP, "hipStreamWaitEvent failed"));
             if (k == 0 && t0) (void)hipEventRecord(t0, c->cs);
             if ((rc = c->tr->all_to_all_v(c->rows_send, xs_cnt.data(), xs_dis.data(), rows_recv, xr_cnt.data(), xr_dis.data(), row_bytes, loop, c->cs)))
                 return broke(rc);
-            if (hipEventRecord(c->ev_x[k], c->cs) != hipSuccess) return broke(fail(COALA_EHIP, "hipEventRecord failed"));
+            x_evs[k] = (k == K - 1 && ev_end_cs) ? ev_end_cs : c->ev_x[k];
+            if (hipEventRecord(x_evs[k], c->cs) != hipSuccess) return broke(fail(COALA_EHIP, "hipEventRecord failed"));
         }
         if (t0 && t1) {
             (void)hipEventRecord(t1, c->cs);
@@ -747,12 +801,19 @@ static int fetch_impl(coala_cache_t* h, coala_comm_t* c, float* out, const int64
             c->prof.calls++;
             c->prof.remote_rows_in += (uint64_t)(n - (int64_t)scnt[me]);
         }
-        // 7. un-permute round by round as the rows arrive
-        for (int k = 0; k < K; ++k) {
-            if (hipStreamWaitEvent(st, c->ev_x[k], 0) != hipSuccess) return broke(fail(COALA_EHIP, "hipStreamWaitEvent failed"));
+        // 7. un-permute round by round as the rows arrive (bucketed: nothing to un-permute, and the communicator's stream completes its rounds
+        //    in order -- the caller's stream waits for the last one only; the workspaces are safe to reuse behind that wait)
+        for (int k = (bucketed && !c->plain_events) ? K - 1 : 0; k < K; ++k) {
+            if (hipStreamWaitEvent(st, x_evs[k], 0) != hipSuccess) return broke(fail(COALA_EHIP, "hipStreamWaitEvent failed"));
             if (!bucketed && (rc = coala_cache_scatter_ranges(h, out, c->rows_recv, c->map, sb.data() + (size_t)k * G, se.data() + (size_t)k * G, G, st)))
                 return broke(rc);
         }
+    }
+    if (ev_mode) {
+        c->last_ev[0] = ev_begin;
+        c->last_ev[1] = ev_end_st;
+        c->last_ev[2] = exchange_rows ? ev_end_cs : nullptr;
+        c->fev_calls++;
     }
     return COALA_OK;
 }

@@ -241,6 +241,15 @@ int coala_cache_last_fetch_events(const coala_cache_t* h, void** begin_ev, void*
 int coala_stream_wait_event(void* stream, void* event);
 int coala_event_elapsed_ms(void* begin_ev, void* end_ev, int wait, float* ms_out);
 
+/* The same for a fetch over a communicator (opt-in; bucketed fetches): with coala_comm_fetch_events(c, 1) a bucketed fetch carries a begin
+ * event on its probe launch and an end event on the last fill launch of the caller's stream, and records a second end event behind the last
+ * row round on the communicator's own stream -- no packet of theirs on the caller's stream.  coala_comm_last_fetch_events hands out the three
+ * (owned by the communicator, valid for 2048 fetches; end_ev_comm is NULL for a communicator of one rank; all NULL after a routed fetch or an
+ * empty batch: the caller then records its own).  The rows are complete once BOTH end events are; begin -> end_ev_comm is the duration a timer
+ * wants.  Independently of this switch the fetch puts its internal hand-over events (fill of round k -> row round k) on the fill launches. */
+int coala_comm_fetch_events(coala_comm_t* c, int enable);
+int coala_comm_last_fetch_events(const coala_comm_t* c, void** begin_ev, void** end_ev_stream, void** end_ev_comm);
+
 /* Timing of the row exchange (all rounds of a fetch, HIP events on the communicator's stream; includes any wait for the fill of
  * a later round): enable = 1 / 0 switches it, -1 leaves it; out (nullable) receives the totals since the last reset. */
 typedef struct coala_comm_profile {

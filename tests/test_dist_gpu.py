@@ -678,9 +678,25 @@ def test_native_fetch_rccl_one_rank_self_loopback(hiplib, oracle, dim, rounds, b
                     stream.synchronize()
                     with torch.cuda.stream(side):
                         ticket = ex.counts_begin(cnt.data_ptr())
+                ex.fetch_events(True)            # begin / end events ride on the fetch's own launches (coala_comm_fetch_events)
                 ex.fetch_bucketed(caches[0], out.data_ptr() if n else 0, idx.data_ptr() if n else 0, n, cnt.data_ptr(), ticket=ticket)
+                begin, end_st, end_cs = ex.last_fetch_events()
+                if n:
+                    # a consumer on another stream that waits for BOTH end events -- and for nothing else -- sees every row
+                    assert begin and end_st and end_cs
+                    copy = torch.full((n, dim), -5.0, dtype=torch.float32, device="cuda")
+                    with torch.cuda.stream(side):
+                        hiplib.stream_wait_event(end_st)
+                        hiplib.stream_wait_event(end_cs)
+                        copy.copy_(out[:n])
+                    side.synchronize()
+                    assert copy.cpu().numpy().tobytes() == feat[ids].tobytes(), f"step {step}: the consumer ran ahead of the fetch"
+                    assert hiplib.event_elapsed_ms(begin, end_cs, wait=True) > 0.0
+                else:
+                    assert (begin, end_st, end_cs) == (None, None, None)
             else:
                 ex.fetch(caches[0], out.data_ptr() if n else 0, idx.data_ptr() if n else 0, n)
+                assert ex.last_fetch_events() == (None, None, None)      # routed fetches record nothing of the kind
             stream.synchronize()
             want = oracle.dist_fetch(orcs, [ids], oracle.SCHED_HITS_FIRST)[0]
             assert out[:n].cpu().numpy().tobytes() == feat[ids].tobytes() == want.tobytes(), f"step {step}: rows differ"

@@ -1200,13 +1200,15 @@ int coala_cache_geometry(const coala_cache_t* h, coala_cache_geometry_t* out) {
 enum { kPhaseProbe = 1, kPhaseFill = 2, kPhaseBoth = 3 };
 
 // ext_begin / ext_end (library-internal callers: the distributed fetch): events to put ON the probe's launch (its begin) / on the LAST fill
-// launch of this call (its end) instead of recording them behind it; *attached says which of the two found a launch to ride on (bit 0 / bit 1) --
-// a profiling handle uses the dispatches' event slots itself, a call may launch nothing -- so that the caller records the others the plain way.
+// launch of this call (its end) instead of recording them behind it.  rode[0] / rode[1] receive the event that really rides on that launch:
+// the caller's, or -- a profiling handle uses the dispatches' event slots for its own pairs -- the handle's profiling event of that launch
+// (good for a stream to wait on; it returns to a pool later, so not for timing), or NULL when the call launched nothing there: the caller
+// then records its event the plain way.
 static int read_feature_impl(coala_cache_t* h, float* out, const int64_t* idx, int64_t n, void* stream, bool force_dist,
                              int phases, const int64_t* begins, const int64_t* ends, int n_ranges,
                              const coala_row_redirect_t* redirect, hipEvent_t ext_begin = nullptr, hipEvent_t ext_end = nullptr,
-                             int* attached = nullptr) {
-    if (attached) *attached = 0;
+                             hipEvent_t* rode = nullptr) {
+    if (rode) rode[0] = rode[1] = nullptr;
     if (!h) return fail(COALA_EINVAL, "null handle");
     h->last_begin = h->last_end = nullptr; // (set again below when this call launches a whole read with its events attached)
     if (n < 0 || n > 0x7FFFFFFFll) return fail(COALA_EINVAL, "n=%lld out of range", (long long)n);
@@ -1306,6 +1308,7 @@ static int read_feature_impl(coala_cache_t* h, float* out, const int64_t* idx, i
         // K1: 2-wave blocks, every wave resident; grid-stride over the chunks
         if (phases & kPhaseProbe) {
             ProfScope ps(h, s, 0, (uint64_t)n, fe_begin, nullptr);
+            if (rode) rode[0] = ps.on ? ps.a : fe_begin;
             const bool full = (VEC == 4) && ((int)d.dim == CD);
             auto launch_k1 = [&](auto tag_c, auto np_c) {
                 using TAG = decltype(tag_c);
@@ -1351,7 +1354,9 @@ static int read_feature_impl(coala_cache_t* h, float* out, const int64_t* idx, i
             // verdict tile: 64 rows behind the narrow host-tier grid, one chunk behind the wide HBM-tier grid (see the kernel)
             const int tile_rows = h->k2_tile_rows > 0 ? h->k2_tile_rows : G::R;
             return for_each_range_set(begins, ends, n_ranges, [&](const RangeSet& rs) -> int {
-                ProfScope ps(h, s, 2, 0, nullptr, (++set_no == n_sets) ? fe_end : nullptr);
+                const bool last_set = ++set_no == n_sets;
+                ProfScope ps(h, s, 2, 0, nullptr, last_set ? fe_end : nullptr);
+                if (rode && last_set) rode[1] = ps.on ? ps.b : fe_end;
                 const int64_t tiles = ((int64_t)rs.total + tile_rows - 1) / tile_rows;
                 const dim3 grid(grid_for(tiles, 4, h->k2_grid_cap));
                 if (redir) ps.launch(miss_fill_kernel<CD, VEC, true>, grid, dim3(256), d, idx, out, tile_rows, h->k2_sparse_max, gen, rs, rd);
@@ -1366,8 +1371,6 @@ static int read_feature_impl(coala_cache_t* h, float* out, const int64_t* idx, i
         h->last_begin = fe_begin;
         h->last_end = fe_end;
         h->fev_calls++;
-    } else if (attached) {
-        *attached = ((fe_begin && (phases & kPhaseProbe)) ? 1 : 0) | ((fe_end && n_sets > 0) ? 2 : 0);
     }
     if (phases & kPhaseProbe) h->rows_total += (uint64_t)n;
     if (phases == kPhaseFill) {
@@ -1402,12 +1405,18 @@ int coala_cache_serve_probe_redirect(coala_cache_t* h, float* out, const int64_t
 
 // library-internal (coala_internal.h): the split-phase serve with events on its launches
 int coala_serve_probe_redirect_ev_(coala_cache_t* h, float* out, const int64_t* ids, int64_t n, const coala_row_redirect_t* redirect, void* stream,
-                                   hipEvent_t begin_ev, int* attached) {
-    return read_feature_impl(h, out, ids, n, stream, true, kPhaseProbe, nullptr, nullptr, 0, redirect, begin_ev, nullptr, attached);
+                                   hipEvent_t begin_ev, hipEvent_t* rode) {
+    hipEvent_t r[2];
+    const int rc = read_feature_impl(h, out, ids, n, stream, true, kPhaseProbe, nullptr, nullptr, 0, redirect, begin_ev, nullptr, r);
+    if (rode) *rode = r[0];
+    return rc;
 }
 int coala_serve_fill_ranges_ev_(coala_cache_t* h, float* out, const int64_t* ids, int64_t n, const int64_t* begins, const int64_t* ends, int n_ranges,
-                                void* stream, hipEvent_t end_ev, int* attached) {
-    return read_feature_impl(h, out, ids, n, stream, true, kPhaseFill, begins, ends, n_ranges, nullptr, nullptr, end_ev, attached);
+                                void* stream, hipEvent_t end_ev, hipEvent_t* rode) {
+    hipEvent_t r[2];
+    const int rc = read_feature_impl(h, out, ids, n, stream, true, kPhaseFill, begins, ends, n_ranges, nullptr, nullptr, end_ev, r);
+    if (rode) *rode = r[1];
+    return rc;
 }
 
 int coala_cache_serve_fill(coala_cache_t* h, float* out, const int64_t* ids, int64_t n, int64_t begin, int64_t end, void* stream) {

@@ -731,9 +731,9 @@ static int fetch_impl(coala_cache_t* h, coala_comm_t* c, float* out, const int64
         ev_end_st = c->fev[3 * slot + 1];
         ev_end_cs = c->fev[3 * slot + 2];
     }
-    int att = 0;
-    if ((rc = coala_serve_probe_redirect_ev_(h, c->rows_send, c->recv_ids, (int64_t)total_recv, &rd, st, c->plain_events ? nullptr : ev_begin, &att))) return broke(rc);
-    if (ev_begin && !(att & 1) && hipEventRecord(ev_begin, st) != hipSuccess) return broke(fail(COALA_EHIP, "hipEventRecord failed"));
+    hipEvent_t rode = nullptr;
+    if ((rc = coala_serve_probe_redirect_ev_(h, c->rows_send, c->recv_ids, (int64_t)total_recv, &rd, st, c->plain_events ? nullptr : ev_begin, &rode))) return broke(rc);
+    if (ev_begin && rode != ev_begin && hipEventRecord(ev_begin, st) != hipSuccess) return broke(fail(COALA_EHIP, "hipEventRecord failed"));
     // 6. rounds: fill slice k of every peer's segment on the caller's stream, ship it on the comm stream while slice k+1 fills
     const int K = (G == 1 && !loop) ? 1 : c->rounds;
     const bool exchange_rows = G > 1 || loop;
@@ -762,12 +762,16 @@ static int fetch_impl(coala_cache_t* h, coala_comm_t* c, float* out, const int64
             }
             if (e > b) { fb[nr] = b; fe[nr] = e; ++nr; }
         }
-        // the event the row round k waits for rides on this round's fill launch; the last round's is the fetch's end event on this stream
+        // the event the row round k waits for rides on this round's fill launch (a profiling cache handle lends its own event of that launch);
+        // the last round's is the fetch's end event on this stream
         const bool last = k == K - 1;
         hipEvent_t fill_ev = (last && ev_end_st) ? ev_end_st : (exchange_rows ? c->ev_fill[k] : nullptr);
-        fill_evs[k] = fill_ev;
-        if ((rc = coala_serve_fill_ranges_ev_(h, c->rows_send, c->recv_ids, (int64_t)total_recv, fb.data(), fe.data(), nr, st, c->plain_events ? nullptr : fill_ev, &att))) return broke(rc);
-        if (fill_ev && !(att & 2) && hipEventRecord(fill_ev, st) != hipSuccess) return broke(fail(COALA_EHIP, "hipEventRecord failed"));
+        if ((rc = coala_serve_fill_ranges_ev_(h, c->rows_send, c->recv_ids, (int64_t)total_recv, fb.data(), fe.data(), nr, st, c->plain_events ? nullptr : fill_ev, &rode))) return broke(rc);
+        if (c->plain_events) rode = nullptr;
+        const bool must_be_mine = fill_ev && fill_ev == ev_end_st;    // handed out to the caller: a borrowed event will not do
+        if (fill_ev && (rode == nullptr || (must_be_mine && rode != fill_ev)) && hipEventRecord(fill_ev, st) != hipSuccess)
+            return broke(fail(COALA_EHIP, "hipEventRecord failed"));
+        fill_evs[k] = (rode && !must_be_mine) ? rode : fill_ev;
     }
     if (total_recv == 0) // nothing to serve: the rounds below still run (peers may owe this rank rows)
         for (int k = 0; k < K; ++k) {

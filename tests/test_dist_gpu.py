@@ -670,6 +670,7 @@ def test_native_fetch_rccl_one_rank_self_loopback(hiplib, oracle, dim, rounds, b
             ids = rng.choice(num_rows // 2, size=n, replace=step == 5).astype(np.int64)
             idx = torch.from_numpy(ids).cuda() if n else torch.zeros(0, dtype=torch.int64, device="cuda")
             out = torch.full((max(n, 1), dim), -3.0, dtype=torch.float32, device="cuda")
+            copy = torch.full((max(n, 1), dim), -5.0, dtype=torch.float32, device="cuda")   # (filled BEFORE the fetch: the consumer below must not race its fill)
             stream.synchronize()
             if bucketed:
                 cnt = torch.tensor([n], dtype=torch.int64, device="cuda")
@@ -684,13 +685,12 @@ def test_native_fetch_rccl_one_rank_self_loopback(hiplib, oracle, dim, rounds, b
                 if n:
                     # a consumer on another stream that waits for BOTH end events -- and for nothing else -- sees every row
                     assert begin and end_st and end_cs
-                    copy = torch.full((n, dim), -5.0, dtype=torch.float32, device="cuda")
                     with torch.cuda.stream(side):
                         hiplib.stream_wait_event(end_st)
                         hiplib.stream_wait_event(end_cs)
-                        copy.copy_(out[:n])
+                        copy[:n].copy_(out[:n])
                     side.synchronize()
-                    assert copy.cpu().numpy().tobytes() == feat[ids].tobytes(), f"step {step}: the consumer ran ahead of the fetch"
+                    assert copy[:n].cpu().numpy().tobytes() == feat[ids].tobytes(), f"step {step}: the consumer ran ahead of the fetch"
                     assert hiplib.event_elapsed_ms(begin, end_cs, wait=True) > 0.0
                 else:
                     assert (begin, end_st, end_cs) == (None, None, None)

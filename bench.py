@@ -1251,10 +1251,28 @@ def run_epoch_leg(args, comm, graph, sampler, table, device, fanout, steps_per_e
                 pg = dist.new_group(backend="gloo") if single_dev else None
                 model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev_index], process_group=pg)
             opt = _adam(model.parameters())
+            # A leg that is merely SLOW must not end as a watchdog failure: half of what the leg may take at most is a soft limit, checked on
+            # the host every 64 steps -- one decision for all ranks (the loop is full of collectives) -- after which the leg stops and says so.
+            soft_end = time.time() + 0.5 * min(args.epoch_timeout, guard.remaining() if guard is not None else args.epoch_timeout)
+
+            def out_of_time():
+                late = time.time() > soft_end
+                if world > 1:
+                    f = torch.tensor([1 if late else 0], dtype=torch.int32)
+                    dist.all_reduce(f, op=dist.ReduceOp.MAX, group=comm.local_gloo_gather)
+                    late = bool(int(f[0]))
+                return late
             if full:  # one whole epoch from a cold cache, as the reference's "Epoch Time" of epoch 0
-                steps, secs, nodes = train_steps(loader, model, opt, 1 << 60, device)
+                steps, secs, nodes = train_steps(loader, model, opt, 1 << 60, device, stop_check=out_of_time)
                 secs, nodes = across_ranks(secs, nodes)
                 ms = secs / max(steps, 1) * 1e3
+                if steps < steps_per_epoch - 1:   # the soft limit cut the epoch short: extrapolated, and labelled so
+                    out[name] = {"steps": steps, "ms_per_step": round(ms, 3), "epoch_time_s_extrapolated": round(ms * steps_per_epoch / 1e3, 2),
+                                 "cut_short": f"stopped after {steps} of {steps_per_epoch} steps at the leg's soft time limit; from a cold cache"}
+                    log(f"[{name}] Epoch Time: {ms * steps_per_epoch / 1e3:.2f} (extrapolated: the leg stopped after {steps} steps at its soft time limit)")
+                    loader.close()
+                    del loader, nd
+                    continue
                 out[name] = {"steps": steps, "ms_per_step": round(ms, 3), "epoch_time_s_measured": round(secs, 2),
                              "sampled_nodes": int(nodes)}
                 log(f"[{name}] Epoch Time: {secs:.2f}   Number of sampled nodes : {nodes}   ({steps} steps, {ms:.3f} ms/step)")
@@ -1263,15 +1281,18 @@ def run_epoch_leg(args, comm, graph, sampler, table, device, fanout, steps_per_e
                     loader.print_stats()
                 del loader, nd
                 continue
-            train_steps(loader, model, opt, 100, device)                       # warm the cache and the allocator
-            steps, secs, nodes = train_steps(loader, model, opt, epoch_steps, device)
+            train_steps(loader, model, opt, 100, device, stop_check=out_of_time)                       # warm the cache and the allocator
+            steps, secs, nodes = train_steps(loader, model, opt, epoch_steps, device, stop_check=out_of_time)
             secs, nodes = across_ranks(secs, nodes)
             ms = secs / max(steps, 1) * 1e3
             out[name] = {"steps": steps, "ms_per_step": round(ms, 3), "epoch_time_s_extrapolated": round(ms * steps_per_epoch / 1e3, 2),
                          "sampled_nodes_per_step": round(nodes / max(steps, 1), 1)}
             log(f"[{name}] Epoch Time: {ms * steps_per_epoch / 1e3:.2f} (extrapolated from {steps} steps, {ms:.3f} ms/step)")
-            for _ in loader:  # drain the epoch so that the producer thread and the distributor threads end cleanly
-                pass
+            if prefetch and world > 1:
+                for _ in loader:  # a producer thread may be collectives ahead of its consumer, differently on every rank: run the epoch out
+                    pass
+            else:
+                loader.close()    # the one-thread loader leaves at the same step on every rank: what it has enqueued is symmetric
             del loader, nd
     return out
 

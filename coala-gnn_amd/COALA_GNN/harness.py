@@ -24,8 +24,10 @@ class SageMean(torch.nn.Module):
         return h
 
 
-def train_steps(loader, model, optimizer, max_steps, device):
-    """Runs up to max_steps iterations of the reference's training loop body; returns (steps, seconds, sampled_nodes)."""
+def train_steps(loader, model, optimizer, max_steps, device, stop_check=None, check_every=64):
+    """Runs up to max_steps iterations of the reference's training loop body; returns (steps, seconds, sampled_nodes).
+    stop_check (optional): called every check_every steps on the host; a true answer ends the loop early (a caller with a time limit; in a
+    multi-rank run it must give every rank the same answer at the same step -- the loop is full of collectives)."""
     loss_fn = torch.nn.CrossEntropyLoss()
     steps = nodes = 0
     torch.cuda.synchronize()
@@ -40,6 +42,8 @@ def train_steps(loader, model, optimizer, max_steps, device):
         optimizer.step()
         steps += 1
         if steps >= max_steps:
+            break
+        if stop_check is not None and steps % check_every == 0 and stop_check():
             break
     torch.cuda.synchronize()
     return steps, time.perf_counter() - t0, nodes

@@ -1253,7 +1253,10 @@ def run_epoch_leg(args, comm, graph, sampler, table, device, fanout, steps_per_e
             opt = _adam(model.parameters())
             # A leg that is merely SLOW must not end as a watchdog failure: half of what the leg may take at most is a soft limit, checked on
             # the host every 64 steps -- one decision for all ranks (the loop is full of collectives) -- after which the leg stops and says so.
-            soft_end = time.time() + 0.5 * min(args.epoch_timeout, guard.remaining() if guard is not None else args.epoch_timeout)
+            soft_s = 0.5 * min(args.epoch_timeout, guard.remaining() if guard is not None else args.epoch_timeout)
+            if os.environ.get("COALA_BENCH_SOFT_LIMIT_S"):     # test hook: the soft limit alone, without shrinking the watchdog's
+                soft_s = float(os.environ["COALA_BENCH_SOFT_LIMIT_S"])
+            soft_end = time.time() + soft_s
 
             def out_of_time():
                 late = time.time() > soft_end
@@ -1270,7 +1273,11 @@ def run_epoch_leg(args, comm, graph, sampler, table, device, fanout, steps_per_e
                     out[name] = {"steps": steps, "ms_per_step": round(ms, 3), "epoch_time_s_extrapolated": round(ms * steps_per_epoch / 1e3, 2),
                                  "cut_short": f"stopped after {steps} of {steps_per_epoch} steps at the leg's soft time limit; from a cold cache"}
                     log(f"[{name}] Epoch Time: {ms * steps_per_epoch / 1e3:.2f} (extrapolated: the leg stopped after {steps} steps at its soft time limit)")
-                    loader.close()
+                    if prefetch and world > 1:
+                        for _ in loader:  # (a producer thread may be collectives ahead of its consumer: run the epoch out)
+                            pass
+                    else:
+                        loader.close()
                     del loader, nd
                     continue
                 out[name] = {"steps": steps, "ms_per_step": round(ms, 3), "epoch_time_s_measured": round(secs, 2),

@@ -113,6 +113,20 @@ def test_bench_extra_legs_are_skipped_when_the_budget_is_short():
     assert d["value"] > 0 and "skipped" in d["epoch"] and "error" not in d
 
 
+def test_bench_epoch_leg_stops_at_its_soft_limit_on_every_rank():
+    """An epoch leg that is merely slow must not end as a watchdog failure: at its soft time limit -- one decision for all ranks, taken on the
+    host every 64 steps -- the leg stops, reports what it measured as an extrapolation labelled `cut_short`, and the run goes on (rc 0)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(COALA_BENCH_SINGLE_DEVICE="1", COALA_BENCH_SOFT_LIMIT_S="0.01")
+    small = [a for a in SMALL]
+    small[small.index("--epoch-steps") + 1] = "-1"        # a whole epoch (86 steps per rank at this size): cut at the first check, step 64
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", *small, "--no-fanout-leg"], capture_output=True, text=True,
+                         timeout=600, env=env)
+    d = _line(out)
+    e = d["epoch"]["serial"]
+    assert e["steps"] == 64 and "cut_short" in e and e["epoch_time_s_extrapolated"] > 0 and "error" not in d
+
+
 def test_bench_fallback_to_torch_transport_two_ranks():
     """The first-minibatch check fails on ONE rank (injected): every rank must agree (flag over the CPU group), drop its exchange and go
     on over the torch transport, and the line says so (COALA_GNN_Manager.py:159-203 is what the fall-back re-creates in Python)."""

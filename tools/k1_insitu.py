@@ -2,7 +2,7 @@
 """probe_gather_kernel IN SITU: the default bench workload (IGB-medium shape, fan-out 5,5, isolated 4 GiB cache, pinned-host cold
 tier), one cache handle per variant (COALA_K1_* environment knobs are read at handle creation), 400 warm-up minibatches, then
 the kernel's average duration over 200 timed minibatches by HIP events attached to its launches (COALA_FLAG_PROFILE) -- i.e. with the cold fill of the
-previous step in front of every launch, which the tools/k1_bench micro-benchmark does not have.
+previous step in front of every launch, which a micro-benchmark over one repeated batch (round 2: profiles/r02_k1_variants.txt) does not have.
 
   python tools/k1_insitu.py "GRID=2048" "GRID=1024" "GRID=2048,PASSES=2" ...      (knob list per variant, comma separated)"""
 import os

@@ -18,7 +18,6 @@ fi
 if [ "${PART:-2}" = "2" ] || [ -z "$PART" ]; then
 bash tools/dist_profile.sh > /dev/null 2>&1; grep -v amdgpu.ids $R/gpurun_out/r02_dist_step_kernels.txt > $O/${ROUND}_dist_step_kernels.txt; echo "dist rc=$?"
 COALA_K1_GRID=8192 bash tools/k1_stages_profile.sh > /dev/null 2>&1; grep -v "amdgpu.ids\|^[EW]2026" $R/gpurun_out/r02_k1_fixed_cost.txt > $O/${ROUND}_k1_fixed_cost.txt; echo "k1 stages rc=$?"
-bash tools/k1_variants.sh > /dev/null 2>&1; cp $R/gpurun_out/r02_k1_variants.txt $O/${ROUND}_k1_variants.txt; echo "k1 variants rc=$?"
 python3 tools/k1_dim_sweep.py 2>&1 | grep -v amdgpu.ids > $O/${ROUND}_k1_hit_sweep.txt; echo "dim sweep rc=$?"
 (for g in 1024 4096 16384 65536; do COALA_K1_GRID=$g python3 tools/k1_big_batch_grid.py 2>&1 | grep "^GRID"; done) > $O/${ROUND}_k1_big_batches.body; echo "k1 big batches rc=$?"
 bash tools/dist_overlap_profile.sh > /dev/null 2>&1; cp $R/gpurun_out/r02_dist_overlap.txt $O/${ROUND}_dist_overlap.body; echo "dist overlap rc=$?"

@@ -47,6 +47,13 @@ class _NativeEvent(object):
             event_elapsed_ms(h, h, wait=True)
 
 
+def _completed(ev):
+    if isinstance(ev, _NativeEvent):
+        from COALA_GNN_Pybind import event_elapsed_ms
+        return all(event_elapsed_ms(h, h, wait=False) is not None for h in ev.handles)
+    return ev.query()
+
+
 def _wait_for(stream, ev):
     if isinstance(ev, _NativeEvent):
         from COALA_GNN_Pybind import stream_wait_event
@@ -200,6 +207,15 @@ class COALA_GNN_DataLoader(torch.utils.data.DataLoader):
             cache_backend=cache_backend, sim_buf=sim_buf, num_rows=num_rows, profile=profile,
             cold_partitioned=cold_partitioned, out_ring=self.prefetch + 2)  # batches alive at once: consumer + queue + producer
         self.COALA_GNN_Manager.sync_on_return = bool(sync_fetch)
+        if not sync_fetch:
+            # the aggregation timer samples: a timing pair on every 16th fetch, counted 16 times (two event packets less between the kernels
+            # of consecutive fetches on the other 15: COALA_GNN_Manager.timing_stride)
+            self.COALA_GNN_Manager.timing_stride = 16
+        # The fetch kernels read tensors the sampler allocated on ITS stream.  record_stream(fetch stream) would make that safe, but the caching
+        # allocator then records one event per tensor ON THE FETCH STREAM when the tensor is freed -- half a dozen barrier packets per minibatch
+        # between the cold fill of one fetch and the probe of the next (30 us of idle link per step: profiles/r04_handover.txt).  Instead the
+        # loader keeps every sampled batch referenced until the event behind its fetch has completed (a host-side query per step).
+        self._retire = collections.deque()
         # the native sampler is stream-aware (it launches on torch's current stream); a foreign sampler keeps the caller's stream
         self._sample_on_side_stream = (not sync_fetch) and str(device).startswith("cuda") and getattr(graph_sampler, "stream_safe", False)
         # The native sampler's sample_end() / sample() return only after the host has seen the completion event of the sample's LAST kernel
@@ -256,10 +272,9 @@ class COALA_GNN_DataLoader(torch.utils.data.DataLoader):
         with torch.cuda.stream(fs):
             if not self._sampler_done_on_host:
                 fs.wait_event(ev_s)
-            for t in _device_tensors(batch):
-                t.record_stream(fs)  # allocated on the sampler's stream, read by the fetch kernels
             item = self.COALA_GNN_Manager.fetch_feature(batch)
             ev_f = self._done_event(fs)
+        self._keep_until_fetched(batch, ev_f)   # allocated on the sampler's stream, read by the fetch kernels
         self.counter += 1
         return item, ev_f
 
@@ -300,6 +315,19 @@ class COALA_GNN_DataLoader(torch.utils.data.DataLoader):
         ev.record(stream)
         return ev
 
+    def _keep_until_fetched(self, batch, ev):
+        """Hold the sampled batch until the event behind its fetch has completed; let go of the ones whose fetch has (in order)."""
+        self._retire.append((ev, batch))
+        while self._retire and _completed(self._retire[0][0]):
+            self._retire.popleft()
+
+    def _retire_all(self):
+        """End of an epoch / close(): nothing of this loader may still be read by a queued fetch when its tensors go back to the allocator."""
+        pending = getattr(self, "_retire", None)
+        if pending:
+            pending[-1][0].synchronize()
+            pending.clear()
+
     def _pump(self):
         """Keep fetch_depth fetches enqueued and one sample launched beyond the last of them (same order of calls as ever: fetch t+1,
         then sample t+2)."""
@@ -315,6 +343,7 @@ class COALA_GNN_DataLoader(torch.utils.data.DataLoader):
     def _end_of_epoch(self):
         self._samples.clear()
         self._fetched.clear()
+        self._retire_all()
         self._sampled = 0
         self.scheduler.drain()  # the reference resets while a distributor thread may still run
         self.node_distributor.reset()
@@ -365,10 +394,9 @@ class COALA_GNN_DataLoader(torch.utils.data.DataLoader):
                 with torch.cuda.stream(self._side_stream):
                     if not self._sampler_done_on_host:
                         self._side_stream.wait_event(ev_s)
-                    for t in _device_tensors(batch):
-                        t.record_stream(self._side_stream)  # allocated on the sampler's stream, read by the fetch kernels
                     item = mgr.fetch_feature(batch)
                     ev_f = self._done_event(self._side_stream)
+                self._keep_until_fetched(batch, ev_f)   # allocated on the sampler's stream, read by the fetch kernels
                 in_flight.append(ev_f)
                 T["fetch"] += clock() - t0
                 nxt = sample_next() if self.counter < self.total_count else None  # overlaps the fetch just enqueued
@@ -402,6 +430,7 @@ class COALA_GNN_DataLoader(torch.utils.data.DataLoader):
                 pass
             self._producer.join(timeout=10)
             self._producer = None
+        self._retire_all()
         self.scheduler.drain()
 
     def __next__(self):  # COALA_GNN_DataLoader.py:149-167

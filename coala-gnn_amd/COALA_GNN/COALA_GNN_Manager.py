@@ -426,13 +426,17 @@ class COALA_GNN_Manager(object):
         # wall time.  False: fully stream-ordered, no host wait; the timer is then fed by a pair of HIP events per call.
         self.sync_on_return = True
         self._agg_events = []
-        # Stream-ordered mode, isolated backend: the begin / end events of a fetch ride on its two kernel dispatches
-        # (coala_cache_fetch_events) instead of being recorded as packets of their own -- on a stream that carries nothing but
-        # fetches, every extra packet between the cold fill of one minibatch and the probe of the next is 6-12 us of idle link.
-        # The same for the native exchange's bucketed fetch (coala_comm_fetch_events): begin on the probe, one end event per stream.
-        # last_done_event: the native end event(s) of the most recent fetch -- a handle or a tuple of handles (None: the caller records one itself).
+        # Stream-ordered mode.  On a stream that carries nothing but fetches, whatever sits between the cold fill of one minibatch and the
+        # probe of the next is idle link (profiles/r04_handover.txt, kernel timestamps, per fetch): plain launches hand over without a gap; ONE
+        # event recorded behind the fetch costs 5.8 us; begin / end events riding on the two dispatches (coala_cache_fetch_events) 14.4 us --
+        # an attached event makes its kernel wait for, and be waited for by, its neighbours; a recorded timing pair + completion event 15.4 us.
+        # So: the aggregation timer's event pair goes on every timing_stride-th fetch only and counts timing_stride times (1 = every fetch, the
+        # default; COALA_GNN_DataLoader sets 16), and completion is left to the caller's one event (last_done_event None) -- except for the
+        # native exchange's bucketed fetch, whose events ride on its own launches (coala_comm_fetch_events: begin on the probe, one end event per
+        # stream; measured against recorded ones in profiles/r04_dist_fetch_packets.txt): last_done_event is then a tuple of native handles.
+        self.timing_stride = 1
+        self._fetch_no = 0
         self.last_done_event = None
-        self._native_events = False
         self._native_exchange_events = False
         if not self.is_simulation:
             raise RuntimeError("sim_buf is None: the NVMe/BaM tier is out of scope here; pass the pinned feature table "
@@ -487,9 +491,6 @@ class COALA_GNN_Manager(object):
                                                   cold_partitioned=cold_partitioned and self.cache_backend == "nccl")
             if cold_partitioned and self.cache_backend == "isolated":
                 raise ValueError("an isolated cache reads every row: it needs the whole cold table, not an owner's shard")
-            if self.cache_backend == "isolated" and not profile and hasattr(self.COALA_GNN_Cache, "fetch_events"):
-                self.COALA_GNN_Cache.fetch_events(True)
-                self._native_events = True
             if self.cache_backend == "nccl":
                 self.exchange = make_exchange()
         else:
@@ -508,9 +509,9 @@ class COALA_GNN_Manager(object):
         fetch_start = time.time()
         ev_pair = None
         self.last_done_event = None
-        native_ev = (not self.sync_on_return) and index_size > 0 and (
-            self._native_events or (self._native_exchange_events and owner_counts_present(self, batch)))
-        if not self.sync_on_return and not native_ev:
+        native_ev = (not self.sync_on_return) and index_size > 0 and self._native_exchange_events and owner_counts_present(self, batch)
+        self._fetch_no += 1
+        if not self.sync_on_return and not native_ev and (self.timing_stride <= 1 or self._fetch_no % self.timing_stride == 0):
             ev_pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev_pair[0].record()
 
@@ -550,26 +551,16 @@ class COALA_GNN_Manager(object):
             torch.cuda.current_stream().synchronize()
             self.aggregation_timer += (time.time() - fetch_start)
         elif native_ev:
-            if self._native_events:
-                a, b = self.COALA_GNN_Cache.last_fetch_events()
-                if b:
-                    self.last_done_event = b
-                    self._agg_events.append((a, b))
-            else:
-                a, b_st, b_cs = self.exchange.last_fetch_events()
-                if b_st:
-                    self.last_done_event = (b_st, b_cs) if b_cs else b_st
-                    self._agg_events.append((a, b_cs or b_st))
-            if self.last_done_event is None:     # (a profiling cache handle, a routed fetch: nothing rode on the launches)
-                ev = torch.cuda.Event()
-                ev.record()
-                self.last_done_event = ev
+            a, b_st, b_cs = self.exchange.last_fetch_events()
+            if b_st:
+                self.last_done_event = (b_st, b_cs) if b_cs else b_st
+                self._agg_events.append((a, b_cs or b_st, 1))
             if len(self._agg_events) >= 64 and (len(self._agg_events) % 64 == 0 or len(self._agg_events) >= 1024):
-                # (the handle keeps 2048 pairs: a host that runs far ahead of the device waits here, at 1024 unread ones)
+                # (the communicator keeps 2048 triples: a host that runs far ahead of the device waits here, at 1024 unread ones)
                 self._fold_events(wait=len(self._agg_events) >= 1024)
-        else:
+        elif ev_pair is not None:
             ev_pair[1].record()
-            self._agg_events.append(ev_pair)
+            self._agg_events.append((ev_pair[0], ev_pair[1], max(1, self.timing_stride)))
             if len(self._agg_events) >= 64:
                 self._fold_events(wait=False)
         return (*batch, return_torch)
@@ -630,20 +621,20 @@ class COALA_GNN_Manager(object):
         """Move finished (start, end) event pairs into the aggregation timer; with wait=True, all of them."""
         from COALA_GNN_Pybind import event_elapsed_ms
         keep = []
-        for a, b in self._agg_events:
-            if isinstance(b, int):           # native pair: begin on the first kernel of the fetch, end on the last
+        for a, b, w in self._agg_events:
+            if isinstance(b, int):           # native handles of a distributed fetch: begin on the probe's launch, end behind its last row round
                 ms = None if keep else event_elapsed_ms(a, b, wait=wait)   # (events of one stream complete in order)
                 if ms is None:
-                    keep.append((a, b))
+                    keep.append((a, b, w))
                 else:
-                    self.aggregation_timer += ms * 1e-3
+                    self.aggregation_timer += ms * 1e-3 * w
                 continue
             if wait:
                 b.synchronize()
             if b.query():
-                self.aggregation_timer += a.elapsed_time(b) * 1e-3
+                self.aggregation_timer += a.elapsed_time(b) * 1e-3 * w
             else:
-                keep.append((a, b))
+                keep.append((a, b, w))
         self._agg_events = keep
 
     def get_cache_data(self, ptr, n_entries=None):

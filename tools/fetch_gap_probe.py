@@ -5,7 +5,7 @@ were doing during every large gap: the host-side calls of the loader (scheduler,
 wall-clock intervals, every garbage collection of the interpreter, every growth of the caching allocator's reserved memory, and the
 completion time of the sample the late fetch waited for, all mapped onto one time axis.  Development tool.
 
-  STEPS=2400 PREFETCH=0|2 REFRESH=10 TRAIN=1 WHY=1 GCFREEZE=1 NATIVE_EVENTS=1|0 SAMPLER_WAIT=0|1 python tools/fetch_gap_probe.py
+  STEPS=2400 PREFETCH=0|2 REFRESH=10 TRAIN=1 WHY=1 GCFREEZE=1 TIMING_STRIDE=1|16 SAMPLER_WAIT=0|1 RECORD_STREAM=0|1 python tools/fetch_gap_probe.py
 """
 import gc
 import os
@@ -41,10 +41,16 @@ kw = {}
 loader = COALA_GNN_DataLoader(SSD_INFO(1, 4096, 1024, 0), nd, g, sampler, batch, dim, fan, 4096, "cuda:0", cache_backend="isolated", sim_buf=table,
                               num_rows=rows, prefetch=int(os.environ.get("PREFETCH", "2")), refresh_counter=int(os.environ.get("REFRESH", "10")), **kw)
 mgr = loader.COALA_GNN_Manager
-if os.environ.get("NATIVE_EVENTS", "1") == "0":   # A/B: the round-3 form (timing pair + completion event recorded as packets of their own)
-    mgr.COALA_GNN_Cache.fetch_events(False); mgr._native_events = False
+if os.environ.get("TIMING_STRIDE"):                 # 1: a timing pair on every fetch (needed for the gap statistics below); the loader's default is 16
+    mgr.timing_stride = int(os.environ["TIMING_STRIDE"])
 if os.environ.get("SAMPLER_WAIT", "0") == "1":    # A/B: the fetch stream waits for the sampler's stream on the device, as until round 3
     loader._sampler_done_on_host = False
+if os.environ.get("RECORD_STREAM", "0") == "1":   # A/B: the round-3 way of keeping the sampler's tensors alive for the fetch kernels: record_stream on the
+    from COALA_GNN.COALA_GNN_DataLoader import _device_tensors, _loader_streams   # fetch stream -- the allocator then records an event per tensor ON that stream at free time
+    def _old_keep(batch, ev):
+        for t in _device_tensors(batch):
+            t.record_stream(_loader_streams("cuda:0")[0])
+    loader._keep_until_fetched = _old_keep
 pairs = []
 def keep(wait):  # keep every (start, end) event pair instead of folding them away
     pairs.extend(mgr._agg_events); mgr._agg_events = []
@@ -119,14 +125,17 @@ for inp, sd, blocks, feat in loader:
     n += 1
 torch.cuda.synchronize(); dt = clock() - t0
 keep(True)
-print(f"train={train} prefetch={loader.prefetch} native_events={mgr._native_events} sampler_wait={not loader._sampler_done_on_host}: "
+print(f"train={train} prefetch={loader.prefetch} timing_stride={mgr.timing_stride} sampler_wait={not loader._sampler_done_on_host} "
+      f"record_stream_on_fetch_stream={os.environ.get('RECORD_STREAM', '0') == '1'}: "
       f"steady state by the host clock (steps 1200..{n}): {(t0 + dt - t_warm) / (n - 1200) * 1e3:.4f} ms/step" if t_warm else "")
+if mgr.timing_stride > 1:
+    sys.exit(0)
 warm = min(1200, max(0, len(pairs) - 400))  # steady state only
 from COALA_GNN_Pybind import event_elapsed_ms
 def el(a, b):   # ms between two events, torch's or the native handles a fetch carries on its dispatches (valid for 2048 fetches: the steady state fits)
     h = lambda e: e if isinstance(e, int) else int(e.cuda_event)
     return event_elapsed_ms(h(a), h(b), wait=True)
-dur = [el(a, b) for a, b in pairs[warm:]]
+dur = [el(p[0], p[1]) for p in pairs[warm:]]
 gap = [el(pairs[i][1], pairs[i + 1][0]) for i in range(warm, len(pairs) - 1)]
 print(f"train={train} prefetch={loader.prefetch} refresh_counter={loader.refresh_counter} : {n} steps, {dt / n * 1e3:.3f} ms/step overall (cold start included)")
 print(f"  steady state ({len(dur)} fetches): fetch duration mean {st.mean(dur):.4f} ms, median {st.median(dur):.4f} ms; idle gap between fetches mean {st.mean(gap):.4f} ms, "

@@ -599,6 +599,7 @@ def _main_body(args, fanout, world, rank, local_rank, single_dev, dev_index, dev
     cache = manager.COALA_GNN_Cache
     max_rows = manager.max_sample_size
     manager.sync_on_return = False  # stream-ordered fetches: the timed region is bracketed by synchronisations below
+    manager.timing_stride = 0       # nobody reads this manager's aggregation timer: no event pair around the fetches (two packets per step on the stream)
 
     total_steps = args.prewarm + args.warmup + args.steps
 
@@ -1120,6 +1121,7 @@ def run_fanout_leg(args, comm, graph, table, device, fanout, backend, cold_parti
                             MPI_comm_manager=comm, device=device, cache_backend=backend, sim_buf=table, num_rows=args.rows,
                             cold_partitioned=cold_partitioned, exchange=args.exchange)
     mgr.sync_on_return = False
+    mgr.timing_stride = 0
 
     def ids_for(step):
         lo = ((step % max(steps_per_epoch, 1)) * world + rank) * args.batch

@@ -431,7 +431,7 @@ class COALA_GNN_Manager(object):
         # event recorded behind the fetch costs 5.8 us; begin / end events riding on the two dispatches (coala_cache_fetch_events) 14.4 us --
         # an attached event makes its kernel wait for, and be waited for by, its neighbours; a recorded timing pair + completion event 15.4 us.
         # So: the aggregation timer's event pair goes on every timing_stride-th fetch only and counts timing_stride times (1 = every fetch, the
-        # default; COALA_GNN_DataLoader sets 16), and completion is left to the caller's one event (last_done_event None) -- except for the
+        # default; COALA_GNN_DataLoader sets 16; 0 = no timing at all: a caller that never reads the timer), and completion is left to the caller's one event (last_done_event None) -- except for the
         # native exchange's bucketed fetch, whose events ride on its own launches (coala_comm_fetch_events: begin on the probe, one end event per
         # stream; measured against recorded ones in profiles/r04_dist_fetch_packets.txt): last_done_event is then a tuple of native handles.
         self.timing_stride = 1
@@ -511,7 +511,7 @@ class COALA_GNN_Manager(object):
         self.last_done_event = None
         native_ev = (not self.sync_on_return) and index_size > 0 and self._native_exchange_events and owner_counts_present(self, batch)
         self._fetch_no += 1
-        if not self.sync_on_return and not native_ev and (self.timing_stride <= 1 or self._fetch_no % self.timing_stride == 0):
+        if not self.sync_on_return and not native_ev and self.timing_stride >= 1 and self._fetch_no % self.timing_stride == 0:
             ev_pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev_pair[0].record()
 

@@ -225,16 +225,18 @@ int coala_comm_counts_begin(coala_comm_t* c, const int64_t* counts_dev, void* st
 int coala_cache_fetch_distributed_bucketed_ahead(coala_cache_t* h, coala_comm_t* c, float* out, const int64_t* idx, int64_t n,
                                                  int64_t ticket, void* stream);
 /* ------------------------------------------------------------------------------------------------------------
- * Completion and timing of a read WITHOUT packets of their own.  A hipEventRecord is one more barrier packet in the stream's
- * queue; on a stream that carries nothing but the fetches of consecutive minibatches (the loader's fetch stream) every such
- * packet is 6-12 us of idle link between the cold fill of one minibatch and the probe of the next.
- * With coala_cache_fetch_events(h, 1) every coala_cache_read_feature attaches a begin event to its first kernel launch and an
- * end event to its last one (hipExtLaunchKernelGGL: the events ride on the two dispatch packets).  coala_cache_last_fetch_events
- * hands out the pair of the most recent call -- owned by the handle, valid for the next 2048 calls, NULL when that call launched
- * nothing (n = 0), when the handle profiles (COALA_FLAG_PROFILE uses the dispatches' event slots itself) or for the split-phase
- * serve calls: the caller then records an event of its own.  A consumer on another stream waits with coala_stream_wait_event
- * (hipStreamWaitEvent); coala_event_elapsed_ms gives begin -> end in milliseconds (wait = 0: returns 1, no error, while the end
- * event has not completed).  The reference synchronises the device after every call instead (ssd_gnn_cache.cuh:266).
+ * Completion and timing of a read WITHOUT packets of their own.  With coala_cache_fetch_events(h, 1) every coala_cache_read_feature
+ * attaches a begin event to its first kernel launch and an end event to its last one (hipExtLaunchKernelGGL: the events ride on the
+ * two dispatch packets).  coala_cache_last_fetch_events hands out the pair of the most recent call -- owned by the handle, valid for
+ * the next 2048 calls, NULL when that call launched nothing (n = 0), when the handle profiles (COALA_FLAG_PROFILE uses the dispatches'
+ * event slots itself) or for the split-phase serve calls: the caller then records an event of its own.  A consumer on another stream
+ * waits with coala_stream_wait_event (hipStreamWaitEvent); coala_event_elapsed_ms gives begin -> end in milliseconds (wait = 0:
+ * returns 1, no error, while the end event has not completed).  What it costs, by the kernels' own timestamps (profiles/r04_handover.txt):
+ * plain launches hand over from the fill of one read to the probe of the next without a gap; these riding events 14 us per read (an
+ * attached event makes its kernel wait for, and be waited for by, its neighbours); ONE hipEventRecord behind the read 6 us; a recorded
+ * timing pair + completion event 15 us.  So: the cheapest completion signal is one recorded event, and this interface is for per-read
+ * TIMING (what COALA_FLAG_PROFILE does per kernel).  The reference synchronises the device after every call instead
+ * (ssd_gnn_cache.cuh:266).
  * ------------------------------------------------------------------------------------------------------------ */
 int coala_cache_fetch_events(coala_cache_t* h, int enable);
 int coala_cache_last_fetch_events(const coala_cache_t* h, void** begin_ev, void** end_ev);

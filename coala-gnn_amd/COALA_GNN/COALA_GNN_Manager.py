@@ -309,9 +309,13 @@ class NativeExchange(object):
     def rounds(self, k):  # must be set to the same value on every rank, between fetches
         self._capi.check(self._lib.coala_comm_set_rounds(self._h, int(k)))
 
-    def fetch_events(self, enable=True):
-        """coala_comm_fetch_events: a bucketed fetch carries its begin / end events on its own launches (no packets of theirs on the caller's stream)."""
-        self._capi.check(self._lib.coala_comm_fetch_events(self._h, 1 if enable else 0))
+    def fetch_events(self, mode=1):
+        """coala_comm_fetch_events: 1 = a bucketed fetch hands out its end events (one per stream; nothing of them is a packet on the caller's
+        stream), 2 = also a begin event on the probe's launch (for a timer; costs that launch ~5 us), 0 = off."""
+        mode = int(mode)
+        if mode != getattr(self, "_fetch_events_mode", None):
+            self._capi.check(self._lib.coala_comm_fetch_events(self._h, mode))
+            self._fetch_events_mode = mode
 
     def last_fetch_events(self):
         """(begin, end on the caller's stream, end on the communicator's stream) of the most recent fetch as native handles; None where there is none."""
@@ -496,7 +500,7 @@ class COALA_GNN_Manager(object):
         else:
             raise ValueError(f"Unsupported cache backend: {self.cache_backend}")  # the reference prints and returns (:113-115)
         if isinstance(self.exchange, NativeExchange) and not profile:
-            self.exchange.fetch_events(True)
+            self.exchange.fetch_events(1)
             self._native_exchange_events = True
 
     def fetch_feature(self, batch):  # :118-213
@@ -511,7 +515,10 @@ class COALA_GNN_Manager(object):
         self.last_done_event = None
         native_ev = (not self.sync_on_return) and index_size > 0 and self._native_exchange_events and owner_counts_present(self, batch)
         self._fetch_no += 1
-        if not self.sync_on_return and not native_ev and self.timing_stride >= 1 and self._fetch_no % self.timing_stride == 0:
+        sampled = self.timing_stride >= 1 and self._fetch_no % self.timing_stride == 0
+        if native_ev:
+            self.exchange.fetch_events(2 if sampled else 1)      # the begin event rides on the probe only when the timer wants this fetch
+        if not self.sync_on_return and not native_ev and sampled:
             ev_pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev_pair[0].record()
 
@@ -554,7 +561,8 @@ class COALA_GNN_Manager(object):
             a, b_st, b_cs = self.exchange.last_fetch_events()
             if b_st:
                 self.last_done_event = (b_st, b_cs) if b_cs else b_st
-                self._agg_events.append((a, b_cs or b_st, 1))
+                if a:
+                    self._agg_events.append((a, b_cs or b_st, max(1, self.timing_stride)))
             if len(self._agg_events) >= 64 and (len(self._agg_events) % 64 == 0 or len(self._agg_events) >= 1024):
                 # (the communicator keeps 2048 triples: a host that runs far ahead of the device waits here, at 1024 unread ones)
                 self._fold_events(wait=len(self._agg_events) >= 1024)

@@ -286,7 +286,7 @@ struct coala_comm {
     bool loopback = false;          // coala_comm_set_self_loopback
     // coala_comm_fetch_events: begin / end events of a bucketed fetch without packets of their own on the caller's stream; a ring of triples
     // (begin on the probe's launch, end on the last fill launch of the caller's stream, end behind the last row round on the communicator's stream)
-    bool fetch_events = false;
+    int fetch_events = 0;           // 0 off, 1 end events only, 2 begin event too (coala_comm_fetch_events)
     bool plain_events = false;      // development builds, COALA_COMM_PLAIN_EVENTS=1: every event recorded behind its kernel, every round waited for (the round-3 form; tools/dist_packets_probe.py)
     static constexpr int kFetchRing = 2048;
     std::vector<hipEvent_t> fev;    // [3 * kFetchRing], created on first use
@@ -534,7 +534,8 @@ int coala_comm_get_rounds(const coala_comm_t* c) { return c ? c->rounds : 0; }
 
 int coala_comm_fetch_events(coala_comm_t* c, int enable) {
     if (!c) return fail(COALA_EINVAL, "null communicator");
-    c->fetch_events = enable != 0;
+    if (enable < 0 || enable > 2) return fail(COALA_EINVAL, "enable must be 0, 1 or 2");
+    c->fetch_events = enable;
     if (!c->fetch_events) c->last_ev[0] = c->last_ev[1] = c->last_ev[2] = nullptr;
     return COALA_OK;
 }
@@ -727,7 +728,7 @@ static int fetch_impl(coala_cache_t* h, coala_comm_t* c, float* out, const int64
         const size_t slot = (size_t)(c->fev_calls % coala_comm::kFetchRing);
         for (size_t k = 3 * slot; k < 3 * slot + 3; ++k)
             if (!c->fev[k] && hipEventCreate(&c->fev[k]) != hipSuccess) return broke(fail(COALA_EHIP, "hipEventCreate failed"));
-        ev_begin = c->fev[3 * slot];
+        ev_begin = c->fetch_events >= 2 ? c->fev[3 * slot] : nullptr;   // (an event on the probe's launch costs that launch ~5 us: only when asked for)
         ev_end_st = c->fev[3 * slot + 1];
         ev_end_cs = c->fev[3 * slot + 2];
     }

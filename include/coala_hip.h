@@ -243,12 +243,15 @@ int coala_cache_last_fetch_events(const coala_cache_t* h, void** begin_ev, void*
 int coala_stream_wait_event(void* stream, void* event);
 int coala_event_elapsed_ms(void* begin_ev, void* end_ev, int wait, float* ms_out);
 
-/* The same for a fetch over a communicator (opt-in; bucketed fetches): with coala_comm_fetch_events(c, 1) a bucketed fetch carries a begin
- * event on its probe launch and an end event on the last fill launch of the caller's stream, and records a second end event behind the last
- * row round on the communicator's own stream -- no packet of theirs on the caller's stream.  coala_comm_last_fetch_events hands out the three
- * (owned by the communicator, valid for 2048 fetches; end_ev_comm is NULL for a communicator of one rank; all NULL after a routed fetch or an
- * empty batch: the caller then records its own).  The rows are complete once BOTH end events are; begin -> end_ev_comm is the duration a timer
- * wants.  Independently of this switch the fetch puts its internal hand-over events (fill of round k -> row round k) on the fill launches. */
+/* The same for a fetch over a communicator (opt-in; bucketed fetches).  enable = 1: a bucketed fetch hands out two END events -- the one its
+ * last fill launch on the caller's stream carries anyway (the hand-over to the row round), and one recorded behind the last row round on
+ * the communicator's own stream -- so that a consumer's stream can wait for the rows without a completion event recorded on the caller's
+ * stream (the rows are complete once BOTH have completed).  enable = 2: additionally a BEGIN event on the probe's launch, for a timer
+ * (begin -> end_ev_comm); an event on a launch costs that launch about 5 us (profiles/r04_handover.txt), so a caller that samples its
+ * timing asks for it on the sampled fetches only.  coala_comm_last_fetch_events hands out the three (owned by the communicator, valid for
+ * 2048 fetches; begin_ev NULL with enable = 1; end_ev_comm NULL for a communicator of one rank; all NULL after a routed fetch or an empty
+ * batch: the caller then records its own).  Independently of this switch the fetch puts its internal hand-over events (fill of round k ->
+ * row round k) on the fill launches and waits for the last row round only. */
 int coala_comm_fetch_events(coala_comm_t* c, int enable);
 int coala_comm_last_fetch_events(const coala_comm_t* c, void** begin_ev, void** end_ev_stream, void** end_ev_comm);
 

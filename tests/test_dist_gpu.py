@@ -679,7 +679,7 @@ def test_native_fetch_rccl_one_rank_self_loopback(hiplib, oracle, dim, rounds, b
                     stream.synchronize()
                     with torch.cuda.stream(side):
                         ticket = ex.counts_begin(cnt.data_ptr())
-                ex.fetch_events(True)            # begin / end events ride on the fetch's own launches (coala_comm_fetch_events)
+                ex.fetch_events(2)               # begin / end events ride on the fetch's own launches (coala_comm_fetch_events; 1 = end events only)
                 ex.fetch_bucketed(caches[0], out.data_ptr() if n else 0, idx.data_ptr() if n else 0, n, cnt.data_ptr(), ticket=ticket)
                 begin, end_st, end_cs = ex.last_fetch_events()
                 if n:

@@ -81,7 +81,7 @@ def main():
                     stream, side, consumer = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
                     ex, cache = exs[r], caches[r]
                     if arm == "riding":
-                        ex.fetch_events(True)
+                        ex.fetch_events(1)
                     my = batches[r]
                     keep = []
                     with torch.cuda.stream(side):

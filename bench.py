@@ -208,6 +208,10 @@ def parse_args():
                          "line reports that one.  At N > 1 the producer thread would issue the exchange's RCCL collectives while the consumer "
                          "thread issues DDP's all-reduce on torch's communicator -- two communicators driven from two host threads with no "
                          "cross-rank launch order, which RCCL documents as a deadlock risk and which has never run on two physical GPUs")
+    ap.add_argument("--ddp", action="store_true",
+                    help="epoch leg at N > 1: wrap the harness model in torch's DistributedDataParallel (the reference's script does, "
+                         "examples/sbatch_ssd_gnn_train.py:112) instead of averaging the gradients with one all-reduce of a flat buffer per step; "
+                         "DDP costs this 1.6 ms step another 1.0 ms of host time (profiles/r04_ddp_overhead.txt)")
     ap.add_argument("--epoch-timeout", type=float, default=150.0,
                     help="seconds after which an epoch leg is abandoned (never later than the run's --time-budget): the JSON line is printed "
                          "with an error field and every rank exits with code 3")
@@ -1183,11 +1187,13 @@ def run_epoch_leg(args, comm, graph, sampler, table, device, fanout, steps_per_e
     leg is the MAX over ranks."""
     import tempfile
     from COALA_GNN import COALA_GNN_DataLoader, Node_Distributor, SSD_INFO
-    from COALA_GNN.harness import SageMean, train_steps
+    from COALA_GNN.harness import FlatGradAllReduce, SageMean, train_steps
     from COALA_GNN.synthetic import block_colors
     out = {} if out is None else out
+    multi_rank = world > 1 or getattr(args, "rehearsal", False)
     out.update({"model": "GraphSAGE 2-layer mean, hidden 128, 19 classes, Adam (torch; out of scope, harness only)"
-                         + (", DistributedDataParallel" if (world > 1 or getattr(args, "rehearsal", False)) else ""),
+                         + ((", DistributedDataParallel" if args.ddp else ", data-parallel: gradients averaged with ONE all-reduce of a flat buffer per step "
+                             "(--ddp: torch's DistributedDataParallel, +1.0 ms of host time per step)") if multi_rank else ""),
                 "per_step": "distribute + sample + fetch_feature + forward/backward/optimizer", "steps_per_epoch": steps_per_epoch,
                 "cache_backend": backend})
     # serial first: at N>1 the prefetching loader (exchange and DDP collectives issued from two host threads) only runs behind
@@ -1248,10 +1254,14 @@ def run_epoch_leg(args, comm, graph, sampler, table, device, fanout, steps_per_e
                                           prefetch=prefetch, cold_partitioned=cold_partitioned)
             torch.manual_seed(0)  # identical initial weights on every rank
             model = SageMean(args.dim, 128, 19).to(device)
+            grad_sync = None
             if world > 1 or getattr(args, "rehearsal", False):
                 # the development hook (all ranks on one GPU) cannot use RCCL: gradients go through a gloo group there
                 pg = dist.new_group(backend="gloo") if single_dev else None
-                model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev_index], process_group=pg)
+                if args.ddp:
+                    model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev_index], process_group=pg)
+                else:   # one all-reduce of a flat gradient buffer per step (COALA_GNN.harness.FlatGradAllReduce)
+                    grad_sync = FlatGradAllReduce(model, group=pg)
             opt = _adam(model.parameters())
             # A leg that is merely SLOW must not end as a watchdog failure: half of what the leg may take at most is a soft limit, checked on
             # the host every 64 steps -- one decision for all ranks (the loop is full of collectives) -- after which the leg stops and says so.
@@ -1268,7 +1278,7 @@ def run_epoch_leg(args, comm, graph, sampler, table, device, fanout, steps_per_e
                     late = bool(int(f[0]))
                 return late
             if full:  # one whole epoch from a cold cache, as the reference's "Epoch Time" of epoch 0
-                steps, secs, nodes = train_steps(loader, model, opt, 1 << 60, device, stop_check=out_of_time)
+                steps, secs, nodes = train_steps(loader, model, opt, 1 << 60, device, stop_check=out_of_time, grad_sync=grad_sync)
                 secs, nodes = across_ranks(secs, nodes)
                 ms = secs / max(steps, 1) * 1e3
                 if steps < steps_per_epoch - 1:   # the soft limit cut the epoch short: extrapolated, and labelled so
@@ -1290,8 +1300,8 @@ def run_epoch_leg(args, comm, graph, sampler, table, device, fanout, steps_per_e
                     loader.print_stats()
                 del loader, nd
                 continue
-            train_steps(loader, model, opt, 100, device, stop_check=out_of_time)                       # warm the cache and the allocator
-            steps, secs, nodes = train_steps(loader, model, opt, epoch_steps, device, stop_check=out_of_time)
+            train_steps(loader, model, opt, 100, device, stop_check=out_of_time, grad_sync=grad_sync)  # warm the cache and the allocator
+            steps, secs, nodes = train_steps(loader, model, opt, epoch_steps, device, stop_check=out_of_time, grad_sync=grad_sync)
             secs, nodes = across_ranks(secs, nodes)
             ms = secs / max(steps, 1) * 1e3
             out[name] = {"steps": steps, "ms_per_step": round(ms, 3), "epoch_time_s_extrapolated": round(ms * steps_per_epoch / 1e3, 2),

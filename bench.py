@@ -1255,7 +1255,7 @@ def run_epoch_leg(args, comm, graph, sampler, table, device, fanout, steps_per_e
             torch.manual_seed(0)  # identical initial weights on every rank
             model = SageMean(args.dim, 128, 19).to(device)
             grad_sync = None
-            if world > 1 or getattr(args, "rehearsal", False):
+            if (world > 1 or getattr(args, "rehearsal", False)) and os.environ.get("COALA_BENCH_NO_DDP") != "1":   # (the knob of profiles/r04_ddp_overhead.txt: no gradient exchange at all)
                 # the development hook (all ranks on one GPU) cannot use RCCL: gradients go through a gloo group there
                 pg = dist.new_group(backend="gloo") if single_dev else None
                 if args.ddp:

@@ -1220,6 +1220,8 @@ def run_epoch_leg(args, comm, graph, sampler, table, device, fanout, steps_per_e
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return float(tmax[0]), int(t[1])
 
+    # the soft time limit's decision is a collective of its own group: the loader's helper threads use the topology's gloo groups concurrently
+    limit_group = dist.new_group(backend="gloo") if world > 1 else None
     with tempfile.TemporaryDirectory() as tmp:
         color, tk, sc, _ = block_colors(args.rows, nodes_per_color=4096)
         files = [os.path.join(tmp, f) for f in ("color.npy", "topk.npy", "score.npy")]
@@ -1274,7 +1276,7 @@ def run_epoch_leg(args, comm, graph, sampler, table, device, fanout, steps_per_e
                 late = time.time() > soft_end
                 if world > 1:
                     f = torch.tensor([1 if late else 0], dtype=torch.int32)
-                    dist.all_reduce(f, op=dist.ReduceOp.MAX, group=comm.local_gloo_gather)
+                    dist.all_reduce(f, op=dist.ReduceOp.MAX, group=limit_group)
                     late = bool(int(f[0]))
                 return late
             if full:  # one whole epoch from a cold cache, as the reference's "Epoch Time" of epoch 0

@@ -96,17 +96,26 @@ class COALA_GNN_Node_Distribution_Scheduler(object):
         # num_colors + 1 entries: colours run 1..num_colors
         self.cache_meta_tensor = torch.zeros(self.node_distributor.num_colors + 1, dtype=torch.int32)
 
-    def run(self, is_last: bool):  # COALA_GNN_DataLoader.py:27-75
+    def _distribute(self, color_header):
+        """In the distribution helper, on EVERY rank: the domain master parses its domain's share of the next global batch, then the domain's
+        ranks broadcast it among themselves (Shared_Tensor.py:102-103).  The reference broadcasts on the thread that drives the step
+        (COALA_GNN_DataLoader.py:41-44); a gloo broadcast of a domain batch is 0.4-0.6 ms on the host, which a multi-GPU step whose fetch takes
+        half a millisecond cannot hide there.  The group is used by this helper alone."""
         nd = self.node_distributor
         comm = nd.comm_manager
         if comm.is_master:
-            if self.distribute_thread is None:  # first stage of the distribution pipeline
-                self.distribute_thread = self._dist_pool.submit(nd.parse_domain_training_nodes, self.cache_color_gathered_header)
-            self.distribute_thread.result()
-            self.distribute_thread = None
+            nd.parse_domain_training_nodes(color_header)
+        buf = nd.parsed_training_nodes_buffer[nd.parsed_training_nodes_buffer_header]
+        comm.broadcast_training_nodes(buf)
+        return buf
 
-        distributed_node_index = nd.parsed_training_nodes_buffer[nd.parsed_training_nodes_buffer_header]
-        comm.broadcast_training_nodes(distributed_node_index)
+    def run(self, is_last: bool):  # COALA_GNN_DataLoader.py:27-75
+        nd = self.node_distributor
+        comm = nd.comm_manager
+        if self.distribute_thread is None:  # first stage of the distribution pipeline
+            self.distribute_thread = self._dist_pool.submit(self._distribute, self.cache_color_gathered_header)
+        distributed_node_index = self.distribute_thread.result()
+        self.distribute_thread = None
         nd.parsed_training_nodes_buffer_header = (nd.parsed_training_nodes_buffer_header + 1) % 2
 
         if self.metadata_reuse_counter == self.refresh_counter:
@@ -131,8 +140,8 @@ class COALA_GNN_Node_Distribution_Scheduler(object):
                 cache.get_cache_data(self.cache_meta_tensor.data_ptr(), self.cache_meta_tensor.numel())
                 self.cache_meta_gather_thread = self._meta_pool.submit(nd.gather_cache_meta, self.cache_meta_tensor)
 
-        if comm.is_master and not is_last:
-            self.distribute_thread = self._dist_pool.submit(nd.parse_domain_training_nodes, self.cache_color_gathered_header)
+        if not is_last:   # (every rank: the broadcast is part of the helper's task)
+            self.distribute_thread = self._dist_pool.submit(self._distribute, self.cache_color_gathered_header)
 
         self.metadata_reuse_counter += 1
         local_r = comm.local_rank

@@ -145,15 +145,19 @@ class _FakeManager:
         self.COALA_GNN_Cache = _FakeCache(rank, n)
 
 
-def mode_scheduler(two_domains):
-    """Seed distribution pipeline (COALA_GNN_DataLoader.py:27-75, Training_node_distributor.py:40-60)."""
+def mode_scheduler(two_domains, ranks_per_domain=1):
+    """Seed distribution pipeline (COALA_GNN_DataLoader.py:27-75, Training_node_distributor.py:40-60).  ranks_per_domain > 1 with two_domains: 2 domains
+    x K ranks (world 2K) -- the shape of bench.py's colour-affinity leg at N = 2K: the domain master parses, the domain's ranks share the result."""
     from _util import ColorFiles, synth_colors
     from COALA_GNN import MPI_Comm_Manager, Node_Distributor
     from COALA_GNN.COALA_GNN_DataLoader import COALA_GNN_Node_Distribution_Scheduler
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    comm = MPI_Comm_Manager(rank if two_domains else 0)
+    K = ranks_per_domain
+    comm = MPI_Comm_Manager(rank // K if two_domains else 0)
     comm.initialize_nested_process_group("isolated")
-    if two_domains:
+    if two_domains and K > 1:
+        assert (comm.local_size, comm.num_master_process, comm.is_master, comm.master_process_index, comm.local_rank) == (K, world // K, rank % K == 0, rank // K, rank % K)
+    elif two_domains:
         assert (comm.local_size, comm.num_master_process, comm.is_master, comm.master_process_index) == (1, world, True, rank)
     else:
         assert (comm.local_size, comm.num_master_process, comm.local_rank) == (world, 1, rank)
@@ -201,6 +205,8 @@ if __name__ == "__main__":
         mode_scheduler(False)
     elif mode == "sched2":
         mode_scheduler(True)
+    elif mode == "sched2x2":
+        mode_scheduler(True, ranks_per_domain=2)
     else:
         raise SystemExit("unknown mode")
     print(f"rank {os.environ['RANK']} ok")

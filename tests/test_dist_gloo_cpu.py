@@ -51,3 +51,9 @@ def test_scheduler_one_domain_two_ranks(tmp_path):
 
 def test_scheduler_two_domains(tmp_path):
     _launch("sched2", 2, tmp_path)
+
+
+def test_scheduler_two_domains_of_two_ranks(tmp_path):
+    """2 domains x 2 ranks (world 4), the shape of bench.py's colour-affinity leg at N = 4: every domain master parses its domain's share, the
+    broadcast to the domain's second rank runs in the distribution helper of both, every global batch is partitioned exactly in both modes."""
+    _launch("sched2x2", 4, tmp_path)

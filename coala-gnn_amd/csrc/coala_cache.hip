@@ -452,7 +452,8 @@ __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src) {
 
 template <int CD, int VEC, bool REDIR = false, int NP = 4>
 __global__ __launch_bounds__(256) void miss_fill_kernel(CacheDev c, const int64_t* __restrict__ idx, float* __restrict__ out,
-                                                        int tile_rows, int sparse_max, uint32_t gen, RangeSet rs, Redirect rd) {
+                                                        int tile_rows, int sparse_max, uint32_t gen, RangeSet rs, Redirect rd,
+                                                        unsigned long long ticket_base, int n_units) {
     // Works on the batch positions of `rs` (the whole batch = one range, or the slices of a serve split into several fills),
     // walked as one dense virtual index space.  A wave reads the verdicts of tile_rows rows at once (one byte per lane;
     // tile_rows = R or 64) and then works through the tile chunk by chunk (R rows), skipping chunks without a miss on a scalar
@@ -475,11 +476,25 @@ __global__ __launch_bounds__(256) void miss_fill_kernel(CacheDev c, const int64_
     // U verdict loads in flight per wave: the scan of a batch without misses is a chain of load latencies, and with FEW misses every
     // group of U tiles is ranked and streamed as one (below) -- 8 tiles = 512 rows per step (4 until round 3: 2 % misses 56 -> 5x us)
     constexpr int U = 8;
-    for (int64_t tile0 = wave; tile0 < n_tiles; tile0 += n_waves * U) {
+    // Which tiles a wave takes.  Static (n_units = 0): wave w takes tiles w, w + n_waves, ... -- with few waves behind a host tier and a miss count that
+    // varies from tile to tile, the waves' shares of the launch differ by +-15-30 % and the last ones stream alone.  Dynamic (n_units > 0): the tiles are
+    // dealt into n_units >= n_waves units the same way, and a wave claims units from a ticket counter until they are gone (the counter only ever
+    // grows: the host knows that a launch of W waves adds n_units + W to it, and passes where this launch's tickets begin).  Which wave streams which
+    // row never mattered to the result.
+    unsigned long long* ticket = c.stats + 2 * kStatBlocks;
+    const int64_t n_deal = n_units > 0 ? (int64_t)n_units : n_waves;
+    for (int64_t unit = n_units > 0 ? -1 : wave;;) {
+      if (n_units > 0) {
+          unsigned long long t = 0;
+          if (lane == 0) t = atomicAdd(ticket, 1ull);
+          unit = (int64_t)(readlane64(t, 0) - ticket_base);
+          if (unit >= n_units) break;
+      } else if (unit >= n_tiles) break;
+     for (int64_t tile0 = unit; tile0 < n_tiles; tile0 += n_deal * U) {
       uint64_t st_pack = 0; // the U verdict bytes of this lane, one per tile
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-          const int64_t tile = tile0 + u * n_waves;
+          const int64_t tile = tile0 + u * n_deal;
           const uint32_t p = (tile < n_tiles && lane < tile_rows) ? pos_of(rs, (uint32_t)(tile * tile_rows + lane)) : 0xFFFFFFFFu;
           const uint32_t w = (p != 0xFFFFFFFFu) ? c.miss_link[p] : 0u;
           const uint64_t v = (w == 0u) ? 0u : ((w & kLinkMiss) ? 1u : 2u);
@@ -611,7 +626,7 @@ __global__ __launch_bounds__(256) void miss_fill_kernel(CacheDev c, const int64_
           }
           if (u_sel >= 0) {
               for (uint32_t i = 0; i < k; ++i) m_sel &= m_sel - 1;   // the k-th miss of that tile sits in lane ctz(m_sel)
-              const uint32_t pos = pos_of(rs, (uint32_t)((tile0 + u_sel * n_waves) * tile_rows + __builtin_ctzll(m_sel)));
+              const uint32_t pos = pos_of(rs, (uint32_t)((tile0 + u_sel * n_deal) * tile_rows + __builtin_ctzll(m_sel)));
               rank_at(pos);
           }
           stream_holders(total_miss >= 64 ? ~0ull : ((1ull << total_miss) - 1ull));
@@ -623,7 +638,7 @@ __global__ __launch_bounds__(256) void miss_fill_kernel(CacheDev c, const int64_
         const uint64_t tile_mask = __ballot(st == 1);   // (recomputed: mmask[] must not be indexed by a run-time u)
         if (!tile_mask) continue;
         // a lane with a verdict has a valid position (recomputed: cheaper than keeping U of them alive across the loop)
-        const uint32_t pos_l = st ? pos_of(rs, (uint32_t)((tile0 + u * n_waves) * tile_rows + lane)) : 0u;
+        const uint32_t pos_l = st ? pos_of(rs, (uint32_t)((tile0 + u * n_deal) * tile_rows + lane)) : 0u;
         if (__builtin_popcountll(tile_mask) <= sparse_max) {
             // Few misses in this tile: rank every missed row of the tile at once, then stream them R at a time, compacted.
             if (st == 1) rank_at(pos_l);
@@ -646,6 +661,8 @@ __global__ __launch_bounds__(256) void miss_fill_kernel(CacheDev c, const int64_
             }
         }
       }
+     }
+      if (n_units <= 0) break;   // static: the wave's own tiles are done
     }
     // miss / rejected totals (isolated_cache.h:471-472): a running sum per block, owned by that block -- no atomics
     __shared__ uint32_t s_m[256 / 64], s_b[256 / 64];
@@ -842,6 +859,8 @@ struct coala_cache {
     Redirect open_redirect{0, 0, nullptr, nullptr};       // the open batch's redirect (set by the probe, reused by its fills)
     int k2_tile_rows = 0;                 // rows per verdict tile of K2: 64 for a host cold tier, 0 = one chunk (COALA_K2_TILE_ROWS)
     int k2_sparse_max = 0;                // tiles with at most this many misses are streamed compacted (host tier; 0 = never)
+    int k2_unit_tiles = 0;                // host tier: tiles per unit of K2's dynamic deal (0 = static: wave w takes tiles w, w + n_waves, ...)
+    uint64_t k2_tickets = 0;              // where the next K2 launch's tickets begin (a launch of W waves over n units adds n + W)
     int k1_passes = 0;                    // development builds: rows(-pairs) in flight per wave in K1 (COALA_K1_PASSES = 2 | 4 | 8 | 16); 0 = the product's choice per line size
     int k1_grid_cap = 16384;              // K1 blocks: one chunk per wave up to 131,072 rows.  Measured (tools/k1_insitu.py, tools/k1_bench): 28.5 k rows at 32 %
                                           // hits in situ: 2048 blocks -> 22.3 us, 4096 -> 20.7, 8192 -> 20.6; all-hit 36,864 rows: 53.8 / 53.1 / 51.4 us;
@@ -1056,12 +1075,12 @@ int coala_cache_create(const coala_cache_config_t* cfg, coala_cache_t** out) {
         if ((rc = alloc((void**)&d.set_cnt, sets * 8))) break;
         if ((rc = alloc((void**)&d.color_meta, slots * 4))) break;
         if ((rc = alloc((void**)&d.set_head, sets * 8))) break;
-        if ((rc = alloc((void**)&d.stats, kStatBlocks * 2 * 8))) break;
+        if ((rc = alloc((void**)&d.stats, (kStatBlocks * 2 + 1) * 8))) break;   // (+ K2's ticket counter behind the per-block sums)
         if ((rc = alloc((void**)&d.lines, slots * (uint64_t)cd * 4))) break;
         if ((rc = alloc((void**)&h->route_bases, 65 * 8))) break;
         if (hipMemset(d.keys, 0xFF, slots * tag_bytes) != hipSuccess || hipMemset(d.set_cnt, 0, sets * 8) != hipSuccess ||
             hipMemset(d.color_meta, 0, slots * 4) != hipSuccess || hipMemset(d.set_head, 0, sets * 8) != hipSuccess ||
-            hipMemset(d.stats, 0, kStatBlocks * 2 * 8) != hipSuccess) {
+            hipMemset(d.stats, 0, (kStatBlocks * 2 + 1) * 8) != hipSuccess) {
             rc = fail(COALA_EHIP, "hipMemset failed");
             break;
         }
@@ -1109,10 +1128,16 @@ int coala_cache_create(const coala_cache_config_t* cfg, coala_cache_t** out) {
             // tiles with at most 32 of 64 rows missing are streamed compacted (tools/k2_sparse_probe.py, 28.5 k rows x 4 KiB: 32 % misses
             // 52.4 -> 55.2 GB/s, 16 %: 47.4 -> 54.6, 8 %: 42.5 -> 52.1, 4 %: 36 -> 47; the 68 % default batch is unchanged, 48 costs it 1 %)
             h->k2_sparse_max = host_tier ? 32 : 0;
+            // host tier: the tiles are dealt dynamically, one 64-row tile per ticket.  With 80-256 waves and a miss count that varies from tile to tile a
+            // static deal leaves the waves' shares 15-30 % apart and the last ones streaming alone (tools/k2_sparse_probe.py, 28.5 k rows x 4 KiB,
+            // static -> dynamic: 100 % misses 49.3-52.5 -> 56.3-56.7 GB/s, 68 % (the default workload) 55.8-56.1 -> 56.4-56.5, 32 % 52.4-53.3 -> 55.6-56.0,
+            // 16 % (the 8-GPU steady state) 49.6-50.1 -> 55.2-55.3, 8 % 49.2-49.7 -> 53.5-53.6, 2 % 43.4-43.5 -> 45.6-45.8: profiles/r04_k2_dynamic_deal.txt)
+            h->k2_unit_tiles = host_tier ? 1 : 0;
 #ifdef COALA_DEV_KNOBS
             if (const char* e = getenv("COALA_K2_TILE_ROWS")) { int t = atoi(e); if (t == 0 || t == 8 || t == 16 || t == 32 || t == 64) h->k2_tile_rows = t; }
             if (const char* e = getenv("COALA_K2_GRID")) { int g = atoi(e); if (g >= 1 && g <= kStatBlocks) h->k2_grid_cap = g; }
             if (const char* e = getenv("COALA_K2_SPARSE")) { int g = atoi(e); if (g >= 0 && g <= 64) h->k2_sparse_max = g; }
+            if (const char* e = getenv("COALA_K2_UNIT_TILES")) { int g = atoi(e); if (g >= 0 && g <= 64) h->k2_unit_tiles = g; }
 #endif
         }
         if (cfg->max_batch) rc = ensure_scratch(h, cfg->max_batch, nullptr);
@@ -1359,8 +1384,14 @@ static int read_feature_impl(coala_cache_t* h, float* out, const int64_t* idx, i
                 if (rode && last_set) rode[1] = ps.on ? ps.b : fe_end;
                 const int64_t tiles = ((int64_t)rs.total + tile_rows - 1) / tile_rows;
                 const dim3 grid(grid_for(tiles, 4, h->k2_grid_cap));
-                if (redir) ps.launch(miss_fill_kernel<CD, VEC, true>, grid, dim3(256), d, idx, out, tile_rows, h->k2_sparse_max, gen, rs, rd);
-                else ps.launch(miss_fill_kernel<CD, VEC, false>, grid, dim3(256), d, idx, out, tile_rows, h->k2_sparse_max, gen, rs, rd);
+                // dynamic deal: units of k2_unit_tiles tiles, claimed by the waves from a ticket counter (only when there are more units than waves)
+                const int64_t waves = (int64_t)grid.x * 4;
+                int64_t units = h->k2_unit_tiles > 0 ? (tiles + h->k2_unit_tiles - 1) / h->k2_unit_tiles : 0;
+                if (units <= waves || units > 0x7FFFFFFF) units = 0;
+                const unsigned long long base = h->k2_tickets;
+                if (units) h->k2_tickets += (uint64_t)units + (uint64_t)waves;
+                if (redir) ps.launch(miss_fill_kernel<CD, VEC, true>, grid, dim3(256), d, idx, out, tile_rows, h->k2_sparse_max, gen, rs, rd, base, (int)units);
+                else ps.launch(miss_fill_kernel<CD, VEC, false>, grid, dim3(256), d, idx, out, tile_rows, h->k2_sparse_max, gen, rs, rd, base, (int)units);
                 return COALA_OK;
             });
         }

@@ -45,6 +45,7 @@ constexpr uint64_t kEmptyKey = 0xFFFFFFFFFFFFFFFFull; // isolated_cache.h:552
 constexpr uint32_t kLinkMiss = 0x80000000u;            // miss_link: a miss (low 31 bits = chain link)
 constexpr uint32_t kLinkBad = 0x7FFFFFFFu;             // miss_link: id outside [0, num_rows)
 constexpr int kStatBlocks = 2048;                      // upper bound of K2's grid
+constexpr int kFillSlots = 8;                          // fill launches of one batch that can deal their tiles dynamically (a ticket counter each, two batches' worth)
 
 struct CacheDev {
     void* keys;            // [sets*32] tags: uint32_t when every id fits 32 bits (tag32: a set is ONE 128-B line), else uint64_t (256 B)
@@ -248,6 +249,9 @@ __global__ __launch_bounds__(64 * kK1MaxWaves, (k1_min_waves<CD, TAG, FULL, REDI
     using TV = typename TG::vec;
     constexpr int R = G::R;
     static_assert(R <= 32, "per-chunk row masks are 32 bits wide");
+    // the ticket counters of THIS batch's fill launches (K2's dynamic deal): the probe comes before every one of them, and the counters of this
+    // parity were last used two batches ago
+    if (blockIdx.x == 0 && threadIdx.x < kFillSlots) reinterpret_cast<uint32_t*>(c.stats + 2 * kStatBlocks)[(gen & 1u) * kFillSlots + threadIdx.x] = 0u;
     constexpr int TSTEPS = (R + TG::SPL - 1) / TG::SPL; // tag loads per chunk: SPL sets per wave-wide 16-B load (LPS lanes x KPL tags per set)
     int lane = threadIdx.x & 63;
 #ifdef COALA_DEV_KNOBS
@@ -452,8 +456,7 @@ __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src) {
 
 template <int CD, int VEC, bool REDIR = false, int NP = 4>
 __global__ __launch_bounds__(256) void miss_fill_kernel(CacheDev c, const int64_t* __restrict__ idx, float* __restrict__ out,
-                                                        int tile_rows, int sparse_max, uint32_t gen, RangeSet rs, Redirect rd,
-                                                        unsigned long long ticket_base, int n_units) {
+                                                        int tile_rows, int sparse_max, uint32_t gen, RangeSet rs, Redirect rd, int dyn_slot) {
     // Works on the batch positions of `rs` (the whole batch = one range, or the slices of a serve split into several fills),
     // walked as one dense virtual index space.  A wave reads the verdicts of tile_rows rows at once (one byte per lane;
     // tile_rows = R or 64) and then works through the tile chunk by chunk (R rows), skipping chunks without a miss on a scalar
@@ -476,26 +479,31 @@ __global__ __launch_bounds__(256) void miss_fill_kernel(CacheDev c, const int64_
     // U verdict loads in flight per wave: the scan of a batch without misses is a chain of load latencies, and with FEW misses every
     // group of U tiles is ranked and streamed as one (below) -- 8 tiles = 512 rows per step (4 until round 3: 2 % misses 56 -> 5x us)
     constexpr int U = 8;
-    // Which tiles a wave takes.  Static (n_units = 0): wave w takes tiles w, w + n_waves, ... -- with few waves behind a host tier and a miss count that
-    // varies from tile to tile, the waves' shares of the launch differ by +-15-30 % and the last ones stream alone.  Dynamic (n_units > 0): the tiles are
-    // dealt into n_units >= n_waves units the same way, and a wave claims units from a ticket counter until they are gone (the counter only ever
-    // grows: the host knows that a launch of W waves adds n_units + W to it, and passes where this launch's tickets begin).  Which wave streams which
-    // row never mattered to the result.
-    unsigned long long* ticket = c.stats + 2 * kStatBlocks;
-    const int64_t n_deal = n_units > 0 ? (int64_t)n_units : n_waves;
-    for (int64_t unit = n_units > 0 ? -1 : wave;;) {
-      if (n_units > 0) {
-          unsigned long long t = 0;
-          if (lane == 0) t = atomicAdd(ticket, 1ull);
-          unit = (int64_t)(readlane64(t, 0) - ticket_base);
-          if (unit >= n_units) break;
+    // Which tiles a wave takes.  Static (dyn_slot < 0): wave w takes tiles w, w + n_waves, ... -- with few waves behind a host tier and a miss count that
+    // varies from tile to tile, the waves' shares of the launch differ by 15-30 % and the last ones stream alone.  Dynamic: a wave CLAIMS tiles from this
+    // launch's ticket counter until they are gone (the probe of the batch zeroed the batch's counters; which wave streams which row never mattered to
+    // the result).  A claim is ONE tile while the wave finds misses -- the finest deal -- and U consecutive tiles, their verdicts loaded at once, after a
+    // claim that found none: a batch (or a stretch of one) without misses is scanned as fast as by the static deal.
+    uint32_t* ticket = reinterpret_cast<uint32_t*>(c.stats + 2 * kStatBlocks) + (dyn_slot < 0 ? 0 : dyn_slot);
+    const bool dyn = dyn_slot >= 0;
+    const int64_t n_deal = dyn ? 1 : n_waves;
+    int claim = 1;
+    for (int64_t unit = dyn ? -1 : wave;;) {
+      int n_here = U;                       // tiles of this pass: tile0 + u * n_deal, u < n_here
+      if (dyn) {
+          uint32_t t = 0;
+          if (lane == 0) t = atomicAdd(ticket, (uint32_t)claim);
+          unit = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+          if (unit >= n_tiles) break;
+          n_here = claim;
+          claim = U;                        // (back to 1 below as soon as this claim turns out to hold a miss)
       } else if (unit >= n_tiles) break;
-     for (int64_t tile0 = unit; tile0 < n_tiles; tile0 += n_deal * U) {
+     for (int64_t tile0 = unit; tile0 < n_tiles && (!dyn || tile0 == unit); tile0 += n_deal * U) {   // (dynamic: a claim is ONE pass)
       uint64_t st_pack = 0; // the U verdict bytes of this lane, one per tile
 #pragma unroll
       for (int u = 0; u < U; ++u) {
           const int64_t tile = tile0 + u * n_deal;
-          const uint32_t p = (tile < n_tiles && lane < tile_rows) ? pos_of(rs, (uint32_t)(tile * tile_rows + lane)) : 0xFFFFFFFFu;
+          const uint32_t p = (u < n_here && tile < n_tiles && lane < tile_rows) ? pos_of(rs, (uint32_t)(tile * tile_rows + lane)) : 0xFFFFFFFFu;
           const uint32_t w = (p != 0xFFFFFFFFu) ? c.miss_link[p] : 0u;
           const uint64_t v = (w == 0u) ? 0u : ((w & kLinkMiss) ? 1u : 2u);
           st_pack |= v << (8 * u);
@@ -608,6 +616,7 @@ __global__ __launch_bounds__(256) void miss_fill_kernel(CacheDev c, const int64_
           worst = cnt > worst ? cnt : worst;
       }
       if (!total_miss) continue;
+      claim = 1;
       if (total_miss <= 64 && (int)worst <= sparse_max) {
           // Few misses in ALL U tiles (the multi-GPU steady state: the caches of 8 GPUs hold most of the table).  Tile by tile a wave
           // would pay the whole dependency chain -- verdict -> id -> chain walk -> cursor -> PCIe read -> store, ~8 us -- once per
@@ -662,7 +671,7 @@ __global__ __launch_bounds__(256) void miss_fill_kernel(CacheDev c, const int64_
         }
       }
      }
-      if (n_units <= 0) break;   // static: the wave's own tiles are done
+      if (!dyn) break;           // static: the wave's own tiles are done
     }
     // miss / rejected totals (isolated_cache.h:471-472): a running sum per block, owned by that block -- no atomics
     __shared__ uint32_t s_m[256 / 64], s_b[256 / 64];
@@ -859,8 +868,8 @@ struct coala_cache {
     Redirect open_redirect{0, 0, nullptr, nullptr};       // the open batch's redirect (set by the probe, reused by its fills)
     int k2_tile_rows = 0;                 // rows per verdict tile of K2: 64 for a host cold tier, 0 = one chunk (COALA_K2_TILE_ROWS)
     int k2_sparse_max = 0;                // tiles with at most this many misses are streamed compacted (host tier; 0 = never)
-    int k2_unit_tiles = 0;                // host tier: tiles per unit of K2's dynamic deal (0 = static: wave w takes tiles w, w + n_waves, ...)
-    uint64_t k2_tickets = 0;              // where the next K2 launch's tickets begin (a launch of W waves over n units adds n + W)
+    int k2_unit_tiles = 0;                // host tier: 1 = K2 deals its tiles dynamically (0 = static: wave w takes tiles w, w + n_waves, ...)
+    int fill_launches = 0;                // fill launches of the current batch so far: each takes its own ticket counter (kFillSlots per batch)
     int k1_passes = 0;                    // development builds: rows(-pairs) in flight per wave in K1 (COALA_K1_PASSES = 2 | 4 | 8 | 16); 0 = the product's choice per line size
     int k1_grid_cap = 16384;              // K1 blocks: one chunk per wave up to 131,072 rows.  Measured (tools/k1_insitu.py, tools/k1_bench): 28.5 k rows at 32 %
                                           // hits in situ: 2048 blocks -> 22.3 us, 4096 -> 20.7, 8192 -> 20.6; all-hit 36,864 rows: 53.8 / 53.1 / 51.4 us;
@@ -1075,12 +1084,12 @@ int coala_cache_create(const coala_cache_config_t* cfg, coala_cache_t** out) {
         if ((rc = alloc((void**)&d.set_cnt, sets * 8))) break;
         if ((rc = alloc((void**)&d.color_meta, slots * 4))) break;
         if ((rc = alloc((void**)&d.set_head, sets * 8))) break;
-        if ((rc = alloc((void**)&d.stats, (kStatBlocks * 2 + 1) * 8))) break;   // (+ K2's ticket counter behind the per-block sums)
+        if ((rc = alloc((void**)&d.stats, (kStatBlocks * 2 + kFillSlots) * 8))) break;   // (+ K2's ticket counters, 2 x kFillSlots x 4 B, behind the per-block sums)
         if ((rc = alloc((void**)&d.lines, slots * (uint64_t)cd * 4))) break;
         if ((rc = alloc((void**)&h->route_bases, 65 * 8))) break;
         if (hipMemset(d.keys, 0xFF, slots * tag_bytes) != hipSuccess || hipMemset(d.set_cnt, 0, sets * 8) != hipSuccess ||
             hipMemset(d.color_meta, 0, slots * 4) != hipSuccess || hipMemset(d.set_head, 0, sets * 8) != hipSuccess ||
-            hipMemset(d.stats, 0, (kStatBlocks * 2 + 1) * 8) != hipSuccess) {
+            hipMemset(d.stats, 0, (kStatBlocks * 2 + kFillSlots) * 8) != hipSuccess) {
             rc = fail(COALA_EHIP, "hipMemset failed");
             break;
         }
@@ -1137,7 +1146,7 @@ int coala_cache_create(const coala_cache_config_t* cfg, coala_cache_t** out) {
             if (const char* e = getenv("COALA_K2_TILE_ROWS")) { int t = atoi(e); if (t == 0 || t == 8 || t == 16 || t == 32 || t == 64) h->k2_tile_rows = t; }
             if (const char* e = getenv("COALA_K2_GRID")) { int g = atoi(e); if (g >= 1 && g <= kStatBlocks) h->k2_grid_cap = g; }
             if (const char* e = getenv("COALA_K2_SPARSE")) { int g = atoi(e); if (g >= 0 && g <= 64) h->k2_sparse_max = g; }
-            if (const char* e = getenv("COALA_K2_UNIT_TILES")) { int g = atoi(e); if (g >= 0 && g <= 64) h->k2_unit_tiles = g; }
+            if (const char* e = getenv("COALA_K2_UNIT_TILES")) { int g = atoi(e); if (g >= 0 && g <= 1) h->k2_unit_tiles = g; }   // 0: the static deal
 #endif
         }
         if (cfg->max_batch) rc = ensure_scratch(h, cfg->max_batch, nullptr);
@@ -1288,6 +1297,7 @@ static int read_feature_impl(coala_cache_t* h, float* out, const int64_t* idx, i
     int rc = ensure_scratch(h, (uint64_t)n, s);
     if (rc) return rc;
     if (phases & kPhaseProbe) {
+        h->fill_launches = 0;
         if (++h->gen == 0) { // generation wrapped: clear the chain heads and the generation tags of the cursors once
             HIPCHK(hipMemsetAsync(h->d.set_head, 0, h->d.num_sets * 8, s));
             HIPCHK(hipMemset2DAsync(reinterpret_cast<char*>(h->d.set_cnt) + 4, 8, 0, 4, h->d.num_sets, s));
@@ -1384,14 +1394,14 @@ static int read_feature_impl(coala_cache_t* h, float* out, const int64_t* idx, i
                 if (rode && last_set) rode[1] = ps.on ? ps.b : fe_end;
                 const int64_t tiles = ((int64_t)rs.total + tile_rows - 1) / tile_rows;
                 const dim3 grid(grid_for(tiles, 4, h->k2_grid_cap));
-                // dynamic deal: units of k2_unit_tiles tiles, claimed by the waves from a ticket counter (only when there are more units than waves)
+                // dynamic deal (host tier, more tiles than waves, one of the batch's first kFillSlots fill launches): this launch's ticket counter
                 const int64_t waves = (int64_t)grid.x * 4;
-                int64_t units = h->k2_unit_tiles > 0 ? (tiles + h->k2_unit_tiles - 1) / h->k2_unit_tiles : 0;
-                if (units <= waves || units > 0x7FFFFFFF) units = 0;
-                const unsigned long long base = h->k2_tickets;
-                if (units) h->k2_tickets += (uint64_t)units + (uint64_t)waves;
-                if (redir) ps.launch(miss_fill_kernel<CD, VEC, true>, grid, dim3(256), d, idx, out, tile_rows, h->k2_sparse_max, gen, rs, rd, base, (int)units);
-                else ps.launch(miss_fill_kernel<CD, VEC, false>, grid, dim3(256), d, idx, out, tile_rows, h->k2_sparse_max, gen, rs, rd, base, (int)units);
+                int dyn_slot = -1;
+                if (h->k2_unit_tiles > 0 && tiles > waves && tiles < 0x7FFFFFFF && h->fill_launches < kFillSlots)
+                    dyn_slot = (int)((gen & 1u) * kFillSlots) + h->fill_launches;
+                h->fill_launches++;
+                if (redir) ps.launch(miss_fill_kernel<CD, VEC, true>, grid, dim3(256), d, idx, out, tile_rows, h->k2_sparse_max, gen, rs, rd, dyn_slot);
+                else ps.launch(miss_fill_kernel<CD, VEC, false>, grid, dim3(256), d, idx, out, tile_rows, h->k2_sparse_max, gen, rs, rd, dyn_slot);
                 return COALA_OK;
             });
         }

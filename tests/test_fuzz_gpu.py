@@ -25,9 +25,10 @@ KNOBS = {2: {"COALA_K2_TILE_ROWS": "0"}, 3: {"COALA_K2_TILE_ROWS": "16", "COALA_
          # the product takes the loop-free probe+gather kernel on lines of 1 KiB and more and the looping one on 512-B lines (and on batches beyond 1 M chunks):
          # the looping kernel on every line size, the loop-free one on every line size
          11: {"COALA_K1_SINGLE": "0"}, 12: {"COALA_K1_SINGLE": "1"}, 13: {"COALA_K1_SINGLE": "0", "COALA_K1_GRID": "2", "COALA_K1_WAVES": "1"},
-         # the cold fill's dynamic deal: units of 1 / 2 tiles claimed from the ticket counter by a narrow grid, 16-row tiles so that small batches have many units
-         14: {"COALA_K2_UNIT_TILES": "1", "COALA_K2_TILE_ROWS": "16", "COALA_K2_GRID": "1"}, 15: {"COALA_K2_UNIT_TILES": "2", "COALA_K2_TILE_ROWS": "8", "COALA_K2_GRID": "2", "COALA_K2_SPARSE": "5"},
-         16: {"COALA_K2_UNIT_TILES": "0", "COALA_K2_TILE_ROWS": "16", "COALA_K2_GRID": "2"}}   # ... and the static deal (what a wide grid and small batches still take)
+         # the cold fill's dynamic deal (the default behind a host tier) with narrow grids and small tiles, so that small batches have many tiles per wave;
+         # ... and the static deal (what a wide grid and small batches take)
+         14: {"COALA_K2_TILE_ROWS": "16", "COALA_K2_GRID": "1"}, 15: {"COALA_K2_TILE_ROWS": "8", "COALA_K2_GRID": "2", "COALA_K2_SPARSE": "5"},
+         16: {"COALA_K2_UNIT_TILES": "0", "COALA_K2_TILE_ROWS": "16", "COALA_K2_GRID": "2"}}
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])

@@ -5,7 +5,7 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "coala-gnn_amd"))
 if os.environ.get("COALA_K2_UNIT_TILES") is not None and os.environ.get("K2_SPARSE") is None:
-    os.environ["K2_SPARSE"] = "32"             # (the product's threshold: the dynamic deal is a knob of the development library too)
+    os.environ["K2_SPARSE"] = "32"             # (the product's threshold; COALA_K2_UNIT_TILES=0 is the static deal of rounds 1-3, a knob of the development library)
 if os.environ.get("K2_SPARSE") is not None:   # development library: the compaction threshold is a knob there
     os.environ["COALA_HIP_LIB"] = os.path.join(ROOT, "coala-gnn_amd", "lib", "libcoala_hip_dev.so")
     os.environ["COALA_K2_SPARSE"] = os.environ["K2_SPARSE"]

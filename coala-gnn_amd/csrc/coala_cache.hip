@@ -1154,10 +1154,10 @@ int coala_cache_create(const coala_cache_config_t* cfg, coala_cache_t** out) {
             // tiles with at most 32 of 64 rows missing are streamed compacted (tools/k2_sparse_probe.py, 28.5 k rows x 4 KiB: 32 % misses
             // 52.4 -> 55.2 GB/s, 16 %: 47.4 -> 54.6, 8 %: 42.5 -> 52.1, 4 %: 36 -> 47; the 68 % default batch is unchanged, 48 costs it 1 %)
             h->k2_sparse_max = host_tier ? 32 : 0;
-            // host tier: the tiles are dealt dynamically, one 64-row tile per ticket.  With 80-256 waves and a miss count that varies from tile to tile a
-            // static deal leaves the waves' shares 15-30 % apart and the last ones streaming alone (tools/k2_sparse_probe.py, 28.5 k rows x 4 KiB,
-            // static -> dynamic: 100 % misses 49.3-52.5 -> 56.3-56.7 GB/s, 68 % (the default workload) 55.8-56.1 -> 56.4-56.5, 32 % 52.4-53.3 -> 55.6-56.0,
-            // 16 % (the 8-GPU steady state) 49.6-50.1 -> 55.2-55.3, 8 % 49.2-49.7 -> 53.5-53.6, 2 % 43.4-43.5 -> 45.6-45.8: profiles/r04_k2_dynamic_deal.txt)
+            // host tier: the tiles are dealt dynamically (miss_fill_kernel).  With 80-256 waves and a miss count that varies from tile to tile a static deal
+            // leaves the waves' shares 15-30 % apart and the last ones streaming alone (tools/k2_sparse_probe.py, 28.5 k rows x 4 KiB, static -> dynamic:
+            // 100 % misses 52.4 -> 56.7 GB/s, 68 % (the default workload) 55.8 -> 56.3, 32 % 52.7 -> 55.9, 16 % (the 8-GPU steady state) 50.4 -> 54.8,
+            // 8 % 49.7 -> 53.2, 2 % 42.7 -> 45.3; a launch with nothing to fill 4 -> 8 us: profiles/r04_k2_dynamic_deal.txt)
             h->k2_unit_tiles = host_tier ? 1 : 0;
 #ifdef COALA_DEV_KNOBS
             if (const char* e = getenv("COALA_K2_TILE_ROWS")) { int t = atoi(e); if (t == 0 || t == 8 || t == 16 || t == 32 || t == 64) h->k2_tile_rows = t; }

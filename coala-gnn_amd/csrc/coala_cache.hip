@@ -489,23 +489,7 @@ __global__ __launch_bounds__(256) void miss_fill_kernel(CacheDev c, const int64_
     const bool dyn = dyn_slot >= 0;
     const int64_t n_deal = dyn ? 1 : n_waves;
     int claim = 1;
-    // ... and first a look at the verdicts of the wave's STATIC share, U loads at a time: a wave that finds nothing there leaves without touching the
-    // counter, so a launch with nothing to fill (the steady state of a cache that holds the whole table) costs what it cost under the static deal; the
-    // tiles are all dealt by the tickets, whoever looked at them first.
-    bool work = true;
-    if (dyn) {
-        uint32_t anyv = 0;
-        for (int64_t t0 = wave; t0 < n_tiles; t0 += n_waves * U) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int64_t tile = t0 + u * n_waves;
-                const uint32_t p = (tile < n_tiles && lane < tile_rows) ? pos_of(rs, (uint32_t)(tile * tile_rows + lane)) : 0xFFFFFFFFu;
-                anyv |= (p != 0xFFFFFFFFu) ? c.miss_link[p] : 0u;
-            }
-        }
-        work = __ballot(anyv != 0) != 0;
-    }
-    if (work) for (int64_t unit = dyn ? -1 : wave;;) {
+    for (int64_t unit = dyn ? -1 : wave;;) {
       int n_here = U;                       // tiles of this pass: tile0 + u * n_deal, u < n_here
       if (dyn) {
           uint32_t t = 0;

@@ -482,24 +482,27 @@ __global__ __launch_bounds__(256) void miss_fill_kernel(CacheDev c, const int64_
     // Which tiles a wave takes.  Static (dyn_slot < 0): wave w takes tiles w, w + n_waves, ... -- with few waves behind a host tier and a miss count that
     // varies from tile to tile, the waves' shares of the launch differ by 15-30 % and the last ones stream alone.  Dynamic: a wave CLAIMS tiles from this
     // launch's ticket counter until they are gone (the probe of the batch zeroed the batch's counters; which wave streams which row never mattered to
-    // the result).  A claim is ONE tile while the wave finds misses -- the finest deal -- and doubles (2, 4, ... U consecutive tiles, their verdicts
-    // loaded at once) with every claim that found none: a batch, or a stretch of one, without misses is scanned nearly as fast as by the static deal
-    // (no-miss launch 6 us against 4; 11 with one tile per claim throughout), and a sparse one is still dealt tile by tile.
+    // the result).  A claim is as small as it may be while the wave finds misses -- ONE tile for a batch of a few tiles per wave, an eighth of a wave's
+    // even share (up to U tiles) for the big ones -- and doubles, up to 4 U consecutive tiles scanned U at a time, with every claim that found none:
+    // a batch, or a stretch of one, without misses is scanned about as fast as by the static deal, and a sparse one is still dealt finely.
     uint32_t* ticket = reinterpret_cast<uint32_t*>(c.stats + 2 * kStatBlocks) + (dyn_slot < 0 ? 0 : dyn_slot);
     const bool dyn = dyn_slot >= 0;
     const int64_t n_deal = dyn ? 1 : n_waves;
-    int claim = 1;
+    const int64_t even8 = n_tiles / (n_waves * 8);
+    const int claim_min = even8 < 1 ? 1 : (even8 > U ? U : (int)even8);
+    int claim = claim_min;
     for (int64_t unit = dyn ? -1 : wave;;) {
-      int n_here = U;                       // tiles of this pass: tile0 + u * n_deal, u < n_here
+      int64_t claim_end = n_tiles;          // static: the wave's tiles run to the end of the launch
       if (dyn) {
           uint32_t t = 0;
           if (lane == 0) t = atomicAdd(ticket, (uint32_t)claim);
           unit = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)t);
           if (unit >= n_tiles) break;
-          n_here = claim;
-          claim = claim * 2 > U ? U : claim * 2;   // (back to 1 below as soon as this claim turns out to hold a miss)
+          claim_end = unit + claim < n_tiles ? unit + claim : n_tiles;
+          claim = claim * 2 > 4 * U ? 4 * U : claim * 2;   // (back to claim_min below as soon as this claim turns out to hold a miss)
       } else if (unit >= n_tiles) break;
-     for (int64_t tile0 = unit; tile0 < n_tiles && (!dyn || tile0 == unit); tile0 += n_deal * U) {   // (dynamic: a claim is ONE pass)
+     for (int64_t tile0 = unit; tile0 < claim_end; tile0 += n_deal * U) {
+      const int n_here = dyn ? (int)(claim_end - tile0 < U ? claim_end - tile0 : U) : U;   // tiles of this pass: tile0 + u * n_deal, u < n_here
       uint64_t st_pack = 0; // the U verdict bytes of this lane, one per tile
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -617,7 +620,7 @@ __global__ __launch_bounds__(256) void miss_fill_kernel(CacheDev c, const int64_
           worst = cnt > worst ? cnt : worst;
       }
       if (!total_miss) continue;
-      claim = 1;
+      claim = claim_min;
       if (total_miss <= 64 && (int)worst <= sparse_max) {
           // Few misses in ALL U tiles (the multi-GPU steady state: the caches of 8 GPUs hold most of the table).  Tile by tile a wave
           // would pay the whole dependency chain -- verdict -> id -> chain walk -> cursor -> PCIe read -> store, ~8 us -- once per

@@ -252,6 +252,10 @@ __global__ __launch_bounds__(64 * kK1MaxWaves, (k1_min_waves<CD, TAG, FULL, REDI
     // the ticket counters of THIS batch's fill launches (K2's dynamic deal): the probe comes before every one of them, and the counters of this
     // parity were last used two batches ago
     if (blockIdx.x == 0 && threadIdx.x < kFillSlots) reinterpret_cast<uint32_t*>(c.stats + 2 * kStatBlocks)[(gen & 1u) * kFillSlots + threadIdx.x] = 0u;
+    // ... and "this batch has something to fill" (set below by every wave that finds a miss or a rejected id): the flag of the NEXT batch's parity is
+    // cleared here -- its last readers, the fills of the batch before this one, are done -- and this batch's was cleared by the previous probe
+    uint32_t* fill_flag = reinterpret_cast<uint32_t*>(c.stats + 2 * kStatBlocks) + 2 * kFillSlots;
+    if (blockIdx.x == 0 && threadIdx.x == kFillSlots) fill_flag[(gen + 1u) & 1u] = 0u;
     constexpr int TSTEPS = (R + TG::SPL - 1) / TG::SPL; // tag loads per chunk: SPL sets per wave-wide 16-B load (LPS lanes x KPL tags per set)
     int lane = threadIdx.x & 63;
 #ifdef COALA_DEV_KNOBS
@@ -351,6 +355,12 @@ __global__ __launch_bounds__(64 * kK1MaxWaves, (k1_min_waves<CD, TAG, FULL, REDI
                 prev[t] = atomicExch(reinterpret_cast<unsigned long long*>(c.set_head + tags.set[t]), tag);
                 // (the set's round-robin cursor, isolated_cache.h:203, is advanced by K2: an atomicAdd here cost 1.2 us per launch)
             }
+        }
+        {   // one store per wave that has work for K2 (a fill launch of a batch without any leaves at once: the steady state of a cache that holds the table)
+            bool any = false;
+#pragma unroll
+            for (int t = 0; t < TSTEPS; ++t) any = any || imiss_l[t] || bad_l[t];
+            if (NOMISS == 0 && __ballot(any) != 0 && lane == 0) fill_flag[gen & 1u] = 1u;
         }
         if (NOMISS == 12) { // (development) ids + tag sets + the probe
             if ((hit_b[0] ^ bad_b[0]) == 0x123456789ABCDEFull && lead_l[0]) out[0] = 1.f;
@@ -487,6 +497,8 @@ __global__ __launch_bounds__(256) void miss_fill_kernel(CacheDev c, const int64_
     // a batch, or a stretch of one, without misses is scanned about as fast as by the static deal, and a sparse one is still dealt finely.
     uint32_t* ticket = reinterpret_cast<uint32_t*>(c.stats + 2 * kStatBlocks) + (dyn_slot < 0 ? 0 : dyn_slot);
     const bool dyn = dyn_slot >= 0;
+    // nothing to fill in the whole batch (the probe's waves set the flag when they find a miss or a rejected id): no scan at all
+    if (reinterpret_cast<const uint32_t*>(c.stats + 2 * kStatBlocks)[2 * kFillSlots + (gen & 1u)] == 0u) return;
     const int64_t n_deal = dyn ? 1 : n_waves;
     const int64_t even8 = n_tiles / (n_waves * 8);
     const int claim_min = even8 < 1 ? 1 : (even8 > U ? U : (int)even8);
@@ -1088,12 +1100,12 @@ int coala_cache_create(const coala_cache_config_t* cfg, coala_cache_t** out) {
         if ((rc = alloc((void**)&d.set_cnt, sets * 8))) break;
         if ((rc = alloc((void**)&d.color_meta, slots * 4))) break;
         if ((rc = alloc((void**)&d.set_head, sets * 8))) break;
-        if ((rc = alloc((void**)&d.stats, (kStatBlocks * 2 + kFillSlots) * 8))) break;   // (+ K2's ticket counters, 2 x kFillSlots x 4 B, behind the per-block sums)
+        if ((rc = alloc((void**)&d.stats, (kStatBlocks * 2 + kFillSlots + 1) * 8))) break;   // (+ K2's ticket counters, 2 x kFillSlots x 4 B, and the two "something to fill" flags behind the per-block sums)
         if ((rc = alloc((void**)&d.lines, slots * (uint64_t)cd * 4))) break;
         if ((rc = alloc((void**)&h->route_bases, 65 * 8))) break;
         if (hipMemset(d.keys, 0xFF, slots * tag_bytes) != hipSuccess || hipMemset(d.set_cnt, 0, sets * 8) != hipSuccess ||
             hipMemset(d.color_meta, 0, slots * 4) != hipSuccess || hipMemset(d.set_head, 0, sets * 8) != hipSuccess ||
-            hipMemset(d.stats, 0, (kStatBlocks * 2 + kFillSlots) * 8) != hipSuccess) {
+            hipMemset(d.stats, 0, (kStatBlocks * 2 + kFillSlots + 1) * 8) != hipSuccess) {
             rc = fail(COALA_EHIP, "hipMemset failed");
             break;
         }

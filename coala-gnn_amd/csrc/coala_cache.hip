@@ -360,7 +360,9 @@ __global__ __launch_bounds__(64 * kK1MaxWaves, (k1_min_waves<CD, TAG, FULL, REDI
             bool any = false;
 #pragma unroll
             for (int t = 0; t < TSTEPS; ++t) any = any || imiss_l[t] || bad_l[t];
+#ifndef K1_NO_FILL_FLAG   // (development A/B of what the flag costs K1: profiles/r04_k2_dynamic_deal.txt)
             if (NOMISS == 0 && __ballot(any) != 0 && lane == 0) fill_flag[gen & 1u] = 1u;
+#endif
         }
         if (NOMISS == 12) { // (development) ids + tag sets + the probe
             if ((hit_b[0] ^ bad_b[0]) == 0x123456789ABCDEFull && lead_l[0]) out[0] = 1.f;
@@ -498,7 +500,9 @@ __global__ __launch_bounds__(256) void miss_fill_kernel(CacheDev c, const int64_
     uint32_t* ticket = reinterpret_cast<uint32_t*>(c.stats + 2 * kStatBlocks) + (dyn_slot < 0 ? 0 : dyn_slot);
     const bool dyn = dyn_slot >= 0;
     // nothing to fill in the whole batch (the probe's waves set the flag when they find a miss or a rejected id): no scan at all
+#ifndef K1_NO_FILL_FLAG
     if (reinterpret_cast<const uint32_t*>(c.stats + 2 * kStatBlocks)[2 * kFillSlots + (gen & 1u)] == 0u) return;
+#endif
     const int64_t n_deal = dyn ? 1 : n_waves;
     const int64_t even8 = n_tiles / (n_waves * 8);
     const int claim_min = even8 < 1 ? 1 : (even8 > U ? U : (int)even8);

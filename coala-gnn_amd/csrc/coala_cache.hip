@@ -871,7 +871,7 @@ struct coala_cache {
     bool order_set = false;
     hipEvent_t order_ev = nullptr;
     uint64_t table_bytes = 0;
-    int k2_grid_cap = kStatBlocks;        // K2 blocks: 16 when the cold tier is host memory.  The link, not the chip, is the limit, and
+    int k2_grid_cap = kStatBlocks;        // K2 blocks: 24-64 when the cold tier is host memory.  The link, not the chip, is the limit, and
                                           // what matters is the bytes of PCIe reads in flight (blocks x 4 waves x 16 KB): ~1 MB
                                           // already runs the link at 56.0 GB/s; 4 MB (64 blocks) gives 56.6 GB/s but queues every
                                           // other host access of the GPU -- AQL packets, kernargs, completion signals of kernels
@@ -1146,12 +1146,15 @@ int coala_cache_create(const coala_cache_config_t* cfg, coala_cache_t** out) {
             (void)hipGetLastError(); // an unregistered pointer is reported as an error: not ours to keep
             // host tier: ~1 MB of reads in flight (blocks x 4 waves x rows-per-wave x line bytes).  A wave holds 16 KB of 4-KiB lines
             // but only 4 KB of 512-B or 1-KiB lines, and with short lines the per-chunk ranking latency dominates, so the
-            // count scales with the line size: 20 / 32 / 64 / 64 blocks for cache_dim 1024 / 512 / 256 / 128
+            // count scales with the line size: 24 / 32 / 64 / 64 blocks for cache_dim 1024 / 512 / 256 / 128
             // (measured at cache_dim 128, 111 M x 128 table: 32 / 64 / 128 blocks -> 42.9 / 55.2 / 52.7 GB/s; 16 -> 22.4).
             // 4-KiB lines: 16 / 20 / 24 / 32 blocks take 1417 / 1420 / 1445 / 1507 us per fill of the default workload on their own, and
             // 1.550-1.585 / 1.526 / 1.524 / 1.529 ms per step (fill + gap) beside a consumer's training kernels, which stretch the
-            // fill by ~5 %: 20 blocks cost 0.2 % alone and give 1.5 % under load (profiles/r03_k2_grid_under_load.txt)
-            const int host_blocks = std::min(64, std::max(20, 16 * 1024 / (int)d.cache_dim));
+            // fill by ~5 %: 20 blocks cost 0.2 % alone and give 1.5 % under load (profiles/r03_k2_grid_under_load.txt) -- that was the STATIC deal of tiles.
+            // With the dynamic deal (below) a few more blocks cost nothing alone, and what counts is a multiple of the 8 XCDs, whose turn it is block by
+            // block: 24 / 32 blocks run the loader's step in 1.438 / 1.441 ms alone and 1.452 / 1.450 beside the training kernels, 20 / 22 / 26 / 28 blocks in
+            // 1.448 / 1.448 / 1.445 / 1.456 and 1.470-1.479 / 1.467 / 1.467 / 1.461; 40: 1.448 and 1.480 (profiles/r04_k2_grid_under_load.txt)
+            const int host_blocks = std::min(64, std::max(24, 16 * 1024 / (int)d.cache_dim));
             h->k2_grid_cap = host_tier ? host_blocks : kStatBlocks;
             h->k2_tile_rows = host_tier ? 64 : 0;
             // tiles with at most 32 of 64 rows missing are streamed compacted (tools/k2_sparse_probe.py, 28.5 k rows x 4 KiB: 32 % misses

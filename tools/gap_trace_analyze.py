@@ -62,6 +62,24 @@ def main():
         if quiet and noisy:
             print(f"    hand-overs with NO other kernel in them: {len(quiet)}, median {st.median(quiet):.1f} us;   with one: {len(noisy)}, median {st.median(noisy):.1f} us")
         print("    kernels of other queues seen in the gaps: " + ", ".join(f"{k} x{v}" for k, v in busy.most_common(8)))
+    # the steady state's budget per fetch: the two kernels, the two hand-overs, the period -- and what ran beside the probe (it starts together with the consumer's step)
+    d1 = [(e[1] - e[0]) / 1e3 for e in k1]
+    d2 = [(e[1] - e[0]) / 1e3 for e in k2]
+    period = [(k1[i + 1][0] - k1[i][0]) / 1e3 for i in range(len(k1) - 1)]
+    beside = collections.Counter()
+    cov1 = []
+    for e in k1:
+        ov = overlapping(e[0], e[1])
+        for o in ov:
+            beside[o[2]] += 1
+        cov1.append(min(1.0, sum(min(o[1], e[1]) - max(o[0], e[0]) for o in ov) / max(e[1] - e[0], 1)))
+    alone = [d for d, c in zip(d1, cov1) if c == 0]
+    shared = [d for d, c in zip(d1, cov1) if c > 0]
+    print(f"last {len(k1)} fetches: K1 median {st.median(d1):.1f} us (mean {st.mean(d1):.1f}); K2 median {st.median(d2):.1f} us (mean {st.mean(d2):.1f}); "
+          f"K1 start -> next K1 start median {st.median(period):.1f} us (mean {st.mean(period):.1f})")
+    print(f"    K1 launches with NO kernel of another queue beside them: {len(alone)}" + (f", median {st.median(alone):.1f} us" if alone else "") +
+          f";   with one: {len(shared)}" + (f", median {st.median(shared):.1f} us" if shared else "") +
+          ";   beside K1: " + ", ".join(f"{k} x{v}" for k, v in beside.most_common(6)))
     durs = collections.defaultdict(list)
     for e in ev:
         durs[(e[3], e[2])].append((e[1] - e[0]) / 1e3)

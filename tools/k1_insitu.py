@@ -82,12 +82,12 @@ out = outs[0]
 for rep in range(int(os.environ.get("REPS", 2))):
     for v in variants:
         for k in list(os.environ):
-            if k.startswith("COALA_K1_"):
+            if k.startswith("COALA_K1_") or k.startswith("COALA_K2_"):
                 del os.environ[k]
         for kv in v.split(","):
             if kv:
                 k, val = kv.split("=")
-                os.environ["COALA_K1_" + k] = val
+                os.environ[("COALA_" if k.startswith("K2_") else "COALA_K1_") + k] = val   # K2_GRID=24, K2_TILE_ROWS=32: the cold fill's knobs
         cache = P.Isolated_Cache(ctrl, None, 0, 1, cache_mb, table.device_ptr, num_rows=rows, profile=True, sync=False, max_batch=max_rows)
         tagb = cache.geometry().tag_set_bytes
         for b in batches[:420]:

@@ -11,14 +11,14 @@ if os.environ.get("K2_SPARSE") is not None:   # development library: the compact
     os.environ["COALA_K2_SPARSE"] = os.environ["K2_SPARSE"]
 import torch
 import COALA_GNN_Pybind as P
-from COALA_GNN.synthetic import alloc_pinned_table
+from COALA_GNN.synthetic import alloc_pinned_table, feature_rows_torch
 torch.cuda.set_device(0)
 rows, dim, n = 2_000_000, 1024, 28500
 table = alloc_pinned_table(rows, dim, 0, 0)
 ctrl = P.SSD_GNN_SSD_Controllers(1, 4096, 1024, 0, 0, dim, True)
 perm = torch.randperm(rows, device="cuda")
 out = torch.empty((n, dim), dtype=torch.float32, device="cuda")
-print(f"# tools/k2_sparse_probe.py: 28,500-row batch, pinned-host cold tier; K2 by events attached to the launch; compaction threshold {os.environ.get('K2_SPARSE', 'product default')}")
+print(f"# tools/k2_sparse_probe.py: 28,500-row batch, pinned-host cold tier; K2 by events attached to the launch; compaction threshold {os.environ.get('K2_SPARSE', 'product default')}, verdict tile rows {os.environ.get('COALA_K2_TILE_ROWS', 'product default (64)')}")
 for miss_pct in (100, 68, 32, 16, 8, 4, 2):
     res = []
     for rep in range(5):
@@ -33,6 +33,8 @@ for miss_pct in (100, 68, 32, 16, 8, 4, 2):
         cache.read_feature(out.data_ptr(), ids.data_ptr(), n)
         torch.cuda.synchronize()
         p = cache.profile()
+        if rep == 0:   # the rows this launch shape delivered == the table's formula (the knobs of the development library change who streams what, never the result)
+            assert torch.equal(out, feature_rows_torch(ids, dim, 0)), f"rows differ from the table at {miss_pct} % misses"
         res.append(p.fill_ms / max(p.fill_launches, 1) * 1e3)
         cache.close()
     us = sorted(res)[len(res) // 2]
